@@ -1,0 +1,91 @@
+"""Deterministic inputs for the golden GPFQ cases (shared by tools/make_golden.py and the tests).
+
+Inputs are NOT stored in the fixtures: they are regenerated from numpy's PCG64 streams (stable across
+numpy versions and platforms) and checked against the sha256 recorded in each fixture.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# name -> parameters.  bits -> K = 2**(bits-1); step_size (the "step_base" of the driver) = scalar / K.
+# kind "loop": one call of StepAlgorithm._quantize_layer (+ per-group _quantization for U).
+CASES = {}
+
+
+def _add(name, N, d, m, bits=4, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1, first_layer=False,
+         zero_every=0, seed=0):
+    CASES[name] = dict(name=name, N=N, d=d, m=m, bits=bits, scalar=scalar, percentile=percentile, reg=reg,
+                       lamb=lamb, groups=groups, first_layer=first_layer, zero_every=zero_every, seed=seed)
+
+
+# G2: loop parity, shapes x modes x bits
+for (_N, _d, _m) in [(8, 27, 16), (16, 64, 96), (64, 147, 512), (32, 288, 1024)]:
+    for _mode, _reg, _lamb in [("msq", None, 0.0), ("soft", "L1", 0.01), ("hard", "L0", 0.01)]:
+        for _bits in (2, 4):
+            _add("g2_%dx%dx%d_%s_b%d" % (_N, _d, _m, _mode, _bits), _N, _d, _m, bits=_bits, reg=_reg, lamb=_lamb,
+                 first_layer=(_d == 27 or _d == 147))
+# multi-segment rows (m > 1024, not a multiple of 1024) and many second-level lanes
+_add("g2_24x96x2500_msq_b4", 24, 96, 2500)
+_add("g2_8x48x5000_soft_b2", 8, 48, 5000, bits=2, reg="L1", lamb=0.05)
+_add("g2_4x40x3072_msq_b3", 4, 40, 3072, bits=3)
+# G3: dead columns, clipping-heavy alphabet, percentile < 1
+_add("g3_zero_cols", 16, 70, 200, zero_every=7)
+_add("g3_clip_heavy", 16, 64, 128, scalar=0.3)
+_add("g3_percentile95", 16, 80, 160, percentile=0.95)
+_add("g3_percentile95_hard", 12, 60, 150, percentile=0.95, reg="L0", lamb=0.02, bits=3)
+_add("g3_m1", 6, 20, 1)
+_add("g3_N1_d1", 1, 1, 33)
+# G4: grouped convolutions (W [N, d_g], A/X [m, groups*d_g])
+_add("g4_groups2", 16, 36, 120, groups=2)
+_add("g4_groups4_soft", 8, 18, 64, groups=4, reg="L1", lamb=0.01, bits=2)
+_add("g4_depthwise", 12, 9, 300, groups=12)
+_add("g4_depthwise_hard", 6, 25, 90, groups=6, reg="L0", lamb=0.01)
+
+
+def make_inputs(case, seed_offset=0):
+    """W [N, d], A, X [m, groups*d] float32, as SURVEY.md 8(d) prescribes for synthetic activations."""
+    c = case
+    rng = np.random.default_rng(1234567 + 1000 * c["seed"] + seed_offset + (hash_name(c["name"]) % 100000))
+    N, d, m, g = c["N"], c["d"], c["m"], c["groups"]
+    D = g * d
+    W = (rng.standard_normal((N, d)) * np.sqrt(2.0 / d)).astype(np.float32)
+    pre = rng.standard_normal((m, D)).astype(np.float32)
+    if c["first_layer"]:
+        A = pre.copy()
+        X = pre.copy()
+    else:
+        A = np.maximum(pre, 0).astype(np.float32)
+        X = np.maximum(pre + np.float32(0.05) * rng.standard_normal((m, D)).astype(np.float32), 0).astype(np.float32)
+    if c["zero_every"]:
+        X[:, ::c["zero_every"]] = 0.0
+    return W, A, X
+
+
+def hash_name(name):
+    return int(hashlib.sha256(name.encode()).hexdigest()[:8], 16)
+
+
+def inputs_digest(W, A, X):
+    h = hashlib.sha256()
+    for a in (W, A, X):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def load_case(name):
+    """Returns (case dict, inputs (W, A, X), fixture npz dict).  Verifies the input digest."""
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    fx = dict(np.load(path, allow_pickle=False))
+    meta = json.loads(str(fx["meta"]))
+    case = meta["case"]
+    W, A, X = make_inputs(case, meta.get("seed_offset", 0))
+    assert inputs_digest(W, A, X) == meta["inputs_sha256"], "golden input generator drifted for " + name
+    return case, (W, A, X), fx, meta
+
+
+def available_cases():
+    return sorted(n for n in CASES if os.path.exists(os.path.join(GOLDEN_DIR, n + ".npz")))

@@ -1,0 +1,105 @@
+"""The CPU oracle against the golden vectors produced from the imported reference (tools/make_golden.py).
+
+Bar: alphabet indices bit-exact, quantized values bit-exact, residual U within 1e-5.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+
+LOOP_CASES = gi.available_cases()
+
+
+def test_fixtures_present():
+    assert len(LOOP_CASES) == len(gi.CASES), "missing golden fixtures; run tools/make_golden.py in the build container"
+    assert os.path.exists(os.path.join(gi.GOLDEN_DIR, "g1_quantizers.npz"))
+    assert os.path.exists(os.path.join(gi.GOLDEN_DIR, "g5_driver.npz"))
+
+
+def test_quantizer_known_answers(oracle_mod):
+    """step=.25, K=2, lamb=.1 on the hand-picked vector (round-half-up, clipping, -0)."""
+    x = np.array([-1, -.625, -.375, -.125, -.1, -0.0, 0.0, .1, .125, .374, .375, .625, .7, 5], np.float32)
+    q, idx = oracle_mod.quantizer_vec(oracle_mod.MODE_MSQ, 0.25, x, 2)
+    assert np.array_equal(q, np.array([-.5, -.5, -.25, -0., -0., 0, 0, 0, .25, .25, .5, .5, .5, .5], np.float32))
+    assert np.signbit(q[3]) and np.signbit(q[4]) and not np.signbit(q[5])
+    assert list(idx) == [-2, -2, -1, 0, 0, 0, 0, 0, 1, 1, 2, 2, 2, 2]
+    q, _ = oracle_mod.quantizer_vec(oracle_mod.MODE_SOFT, 0.25, x, 2, 0.1)
+    assert np.array_equal(q, np.array([-.5, -.5, -.25, -0., 0, 0, 0, 0, 0, .25, .25, .5, .5, .5], np.float32))
+    q, idx = oracle_mod.quantizer_vec(oracle_mod.MODE_HARD, 0.25, x, 2, 0.1)
+    assert np.allclose(q, np.array([-.6, -.6, -.35, -.1, 0, 0, 0, 0, .1, .35, .35, .6, .6, .6], np.float32), atol=1e-7)
+    assert list(idx) == [-3, -3, -2, -1, 0, 0, 0, 0, 1, 2, 2, 3, 3, 3]
+
+
+def test_quantizers_against_reference_vectors(oracle_mod):
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g1_quantizers.npz"))
+    cfgs = json.loads(str(fx["meta"]))["configs"]
+    for ci, c in enumerate(cfgs):
+        x = fx["x_%d" % ci]
+        for name, mode in (("msq", oracle_mod.MODE_MSQ), ("soft", oracle_mod.MODE_SOFT), ("hard", oracle_mod.MODE_HARD)):
+            q, _ = oracle_mod.quantizer_vec(mode, c["step"], x, c["K"], c["lamb"])
+            ref = fx["%s_%d" % (name, ci)]
+            assert np.array_equal(q.view(np.uint32), ref.view(np.uint32)), (name, ci)   # bitwise, incl. -0
+
+
+@pytest.mark.parametrize("name", LOOP_CASES)
+def test_loop_against_reference(oracle_mod, name):
+    case, (W, A, X), fx, meta = gi.load_case(name)
+    K = 2 ** (case["bits"] - 1)
+    r = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"],
+                                  case["groups"])
+    assert r["step"] == fx["step"]
+    assert np.array_equal(r["idx"], fx["idx"]), "alphabet index mismatch"
+    assert np.array_equal(r["Q"], fx["Q"])
+    assert np.abs(r["U"] - fx["U"]).max() <= 1e-5
+    assert abs(r["quantize_error"] - float(fx["quantize_error"])) <= 1e-4 * float(fx["quantize_error"])
+    assert abs(r["relative_quantize_error"] - float(fx["relative_quantize_error"])) <= 1e-4 * float(
+        fx["relative_quantize_error"])
+    if case["groups"] == 1:
+        assert np.allclose(r["relative_adder"], fx["relative_adder"], rtol=1e-4, atol=1e-6)
+    assert np.abs(r["idx"]).max() <= K + (1 if case["reg"] == "L0" else 0)
+
+
+def test_rows_are_independent(oracle_mod):
+    """Quantizing a row subset == slicing the full result (what makes the neuron shard exact)."""
+    case, (W, A, X), fx, _ = gi.load_case("g2_64x147x512_msq_b4")
+    step = float(fx["step"])
+    Qf, idxf, Uf = oracle_mod.quantization(W, A, X, step, 8)
+    Qs, idxs, Us = oracle_mod.quantization(W[16:40], A, X, step, 8)
+    assert np.array_equal(idxs, idxf[16:40]) and np.array_equal(Us, Uf[16:40]) and np.array_equal(Qs, Qf[16:40])
+
+
+def test_thread_count_does_not_change_results(oracle_mod):
+    case, (W, A, X), fx, _ = gi.load_case("g2_24x96x2500_msq_b4")
+    a = oracle_mod.quantization(W, A, X, float(fx["step"]), 8, nthreads=1)
+    b = oracle_mod.quantization(W, A, X, float(fx["step"]), 8, nthreads=5)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
+def test_initial_residual_and_strided_views(oracle_mod):
+    """_quantization is in place on a caller-provided U (step_algorithm.py:107-108): running columns
+    [0,k) then [k,d) with the carried U equals one full run."""
+    case, (W, A, X), fx, _ = gi.load_case("g2_16x64x96_msq_b4")
+    step = float(fx["step"])
+    Q, idx, U = oracle_mod.quantization(W, A, X, step, 8)
+    k = 23
+    Q1, i1, U1 = oracle_mod.quantization(W[:, :k], A[:, :k], X[:, :k], step, 8)
+    Q2, i2, U2 = oracle_mod.quantization(W[:, k:], A[:, k:], X[:, k:], step, 8, U0=U1)
+    assert np.array_equal(np.concatenate([i1, i2], 1), idx) and np.array_equal(U2, U)
+
+
+def test_stochastic_mode_statistics(oracle_mod):
+    """SGPFQ (step_algorithm.py:7-35): unbiased rounding E[q] = x inside the alphabet, clip outside."""
+    n = 200000
+    step, K = 0.25, 4
+    x = np.full(n, 0.3, np.float32)
+    un = np.random.default_rng(0).random(n).astype(np.float32)
+    q, idx = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, step, x, K, uniform=un)
+    assert set(np.unique(idx)) == {1, 2}
+    assert abs(q.mean() - 0.3) < 2e-3
+    q, idx = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, step, np.array([5.0, -5.0], np.float32), K,
+                                      uniform=np.array([0.3, 0.9], np.float32))
+    assert list(q) == [1.0, -1.0] and list(idx) == [4, -4]
