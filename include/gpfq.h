@@ -1,0 +1,144 @@
+/*
+ * gpfq.h -- C ABI of the MI355X-native GPFQ (greedy path-following quantization) hot path.
+ *
+ * This is the drop-in boundary: a plain C interface (device pointers + sizes + a hipStream_t passed as
+ * void*), with no torch types.  Every entry point names the reference interface it replaces
+ * (reference = YixuanSeanZhou/Quantized_Neural_Nets, file:line under src/).  The Python mirror of the
+ * reference's operator surface (quantized_neural_nets_amd/step_algorithm.py) binds these with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc / torch CUDA tensors) unless the name ends in _host;
+ *   - all matrices are row-major fp32 with an explicit leading dimension in ELEMENTS;
+ *   - every call is asynchronous on `stream` (a hipStream_t; NULL = the legacy default stream);
+ *   - return value 0 = ok, negative = error; gpfq_last_error() gives the message for this thread;
+ *   - nothing is allocated inside a call: the caller provides the workspace (gpfq_workspace_bytes).
+ */
+#ifndef GPFQ_H
+#define GPFQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPFQ_ABI_VERSION 1
+
+/* quantizer selection, step_algorithm.py:198-208 */
+enum {
+    GPFQ_MODE_MSQ = 0,        /* StepAlgorithm._msq                    step_algorithm.py:38-56   */
+    GPFQ_MODE_SOFT = 1,       /* StepAlgorithm._soft_thresholding_msq  step_algorithm.py:84-104  (reg == 'L1') */
+    GPFQ_MODE_HARD = 2,       /* StepAlgorithm._hard_thresholding_msq  step_algorithm.py:59-81   (reg == 'L0') */
+    GPFQ_MODE_STOCHASTIC = 3  /* StepAlgorithm._stochastic_msq         step_algorithm.py:7-35    (counter-based RNG) */
+};
+
+/* kernel family selection (GPFQ_PLAN_AUTO picks from (N, m) -- see DESIGN.md "Kernel plans") */
+enum {
+    GPFQ_PLAN_AUTO = 0,
+    GPFQ_PLAN_STREAM = 1,     /* residual U streamed through HBM/L2 every step (any size)        */
+    GPFQ_PLAN_RESIDENT = 2    /* residual U resident in registers for the whole column loop      */
+};
+
+/* error codes */
+enum {
+    GPFQ_OK = 0,
+    GPFQ_ERR_ARG = -1,        /* bad shape / pointer / enum                                       */
+    GPFQ_ERR_WORKSPACE = -2,  /* workspace too small                                              */
+    GPFQ_ERR_HIP = -3,        /* a HIP runtime call failed (message has hipGetErrorString)        */
+    GPFQ_ERR_UNSUPPORTED = -4 /* plan cannot run this shape (e.g. forced RESIDENT with huge m)    */
+};
+
+int gpfq_abi_version(void);
+const char* gpfq_last_error(void);
+
+/* m rounded up to the segment size (1024) the kernels and the canonical reduction use */
+int64_t gpfq_padded_m(int64_t m);
+
+/*
+ * Bytes of device workspace gpfq_quantize_layer_f32 needs for a layer:
+ * transposed+padded activation columns AT, XT [groups*d_g][m_pad], column norms [groups*d_g].
+ */
+size_t gpfq_workspace_bytes(int64_t N, int64_t d_g, int64_t m, int groups);
+
+/*
+ * Column preparation: AT[t][k] = A[k][t], XT[t][k] = X[k][t] for k < m, zero for m <= k < m_pad, and
+ * nrm2[t] = ||X[:, t]||_2 ** 2 exactly as step_algorithm.py:142 spells it (sqrt of the sum of squares,
+ * squared) with the canonical reduction order.  Replaces the strided column reads of
+ * step_algorithm.py:141-148 (analog_layer_input[:, t], quantized_layer_input[:, t]).
+ *   A, X   [m][lda / ldx]   D = number of columns used (groups * d_g)
+ *   AT, XT [D][m_pad]       nrm2 [D]
+ */
+int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
+                             float* AT, float* XT, float* nrm2, int64_t m_pad, void* stream);
+
+/*
+ * The GPFQ loop on one group, in place on Q and U -- replaces
+ *   StepAlgorithm._quantization(W, Q, U, analog_layer_input, quantized_layer_input, quantizer,
+ *                               step_size, boundary_idx, lamb)            step_algorithm.py:107-148
+ * with the columns already prepared (gpfq_prepare_columns_f32).
+ *   W   [N][ldw]  read only                 Q   [N][ldq]  written (alphabet values, fp32)
+ *   U   [N][ldu]  residual: read as the initial value if u_has_init != 0 (else taken as 0), written at the end
+ *   AT, XT [d][m_pad], nrm2 [d]             idx [N][ldi]  optional alphabet indices (may be NULL)
+ *   idx_bytes 1 (int8, needs K <= 126) or 2 (int16)
+ *   index encoding: msq / soft / stochastic -> k in [-K, K], Q = sign(k)*step*|k|;
+ *                   hard -> 0 or +-(k+1), k in [0, K], Q = +-(lamb + step*k)
+ *   seed, row_id0: key of the counter-based generator of GPFQ_MODE_STOCHASTIC (row_id0 = global index of row 0)
+ *   plan: GPFQ_PLAN_*
+ */
+int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, float* U, int64_t ldu,
+                          int u_has_init, const float* AT, const float* XT, const float* nrm2,
+                          int64_t N, int64_t d, int64_t m, int64_t m_pad,
+                          float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
+                          void* idx, int64_t ldi, int idx_bytes, int plan, void* stream);
+
+/*
+ * One whole layer (all groups in one launch) -- the native part of
+ *   StepAlgorithm._quantize_layer(W, analog_layer_input, quantized_layer_input, m, step_size, boundary_idx,
+ *                                 percentile, reg, lamb, groups, stochastic_quantization, device)
+ *                                                                          step_algorithm.py:151-249
+ * i.e. lines :194-196 (Q, U allocation is the caller's), :212-214 (groups == 1) and :221-237 (grouped loop).
+ * `step` is the final alphabet step (step_algorithm.py:191-192), computed by the caller.
+ *   W, Q [N][d_g] contiguous     U [N][m] contiguous (written; initial residual is 0)
+ *   A, X [m][lda / ldx], group g uses columns [g*d_g, (g+1)*d_g) and rows [g*N/groups, (g+1)*N/groups) of W
+ *   idx  [N][d_g] optional       workspace >= gpfq_workspace_bytes(N, d_g, m, groups), 256-byte aligned
+ *   row_id0: global index of row 0 (keys the stochastic generator when a layer is sharded by rows)
+ */
+int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const float* X, int64_t ldx,
+                            int64_t N, int64_t d_g, int64_t m, int groups,
+                            float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
+                            float* Q, void* idx, int idx_bytes, float* U,
+                            void* workspace, size_t workspace_bytes, int plan, void* stream);
+
+/*
+ * The second half of gpfq_quantize_layer_f32 on its own: all groups of a layer in one launch, on columns
+ * already prepared by gpfq_prepare_columns_f32 with D = groups*d_g (AT, XT [groups*d_g][m_pad], nrm2
+ * [groups*d_g]).  Lets a caller time / overlap the column preparation and the loop separately.
+ */
+int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const float* AT, const float* XT,
+                                      const float* nrm2, int64_t N, int64_t d_g, int64_t m, int64_t m_pad,
+                                      int groups, float step, int K, int mode, float lamb, uint64_t seed,
+                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* stream);
+
+/*
+ * Elementwise quantizer on a device vector (the four quantizers as standalone ops, for known-answer
+ * tests): out[i] = quantizer(step, x[i], K, lamb).  step_algorithm.py:7-104.
+ * uniform: per-element U[0,1) draws for GPFQ_MODE_STOCHASTIC (may be NULL for the other modes).
+ */
+int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, float lamb,
+                       const float* uniform, float* out, int32_t* idx, void* stream);
+
+/*
+ * Row statistic for the alphabet radius, percentile == 1 only: rowmax[i] = max_j |W[i][j]|
+ * (torch.quantile(|W|, 1, axis=1), step_algorithm.py:191).
+ */
+int gpfq_row_absmax_f32(const float* W, int64_t ldw, int64_t N, int64_t d, float* rowmax, void* stream);
+
+/* Writes a one-line description of the plan AUTO would pick; returns the plan id or a negative error. */
+int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, char* buf, size_t buf_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPFQ_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI in include/gpfq.h (libgpfq_hip.so, built in-tree by csrc/Makefile).
+
+The library is the product: if it is missing this module raises at import -- there is no fallback.
+torch is imported first so that the HIP runtime torch bundles (SONAME libamdhip64.so.7) is the one the
+library binds to; streams and device pointers are then shared with torch.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede loading the library, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpfq_hip.so")
+
+MODE_MSQ, MODE_SOFT, MODE_HARD, MODE_STOCHASTIC = 0, 1, 2, 3
+PLAN_AUTO, PLAN_STREAM, PLAN_RESIDENT = 0, 1, 2
+
+EXPORTS = [
+    "gpfq_abi_version", "gpfq_last_error", "gpfq_padded_m", "gpfq_workspace_bytes",
+    "gpfq_prepare_columns_f32", "gpfq_quantization_f32", "gpfq_quantize_layer_f32", "gpfq_quantizer_f32",
+    "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32",
+]
+
+
+class GpfqError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the extension (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-s", "-C", src_dir]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "quantized_neural_nets_amd: %s is missing. Build it with `make -C %s` (hipcc, gfx950) or "
+            "__graft_entry__.build(); there is no CPU fallback." % (LIB_PATH, os.path.join(_HERE, "csrc")))
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i64, u64, f32, i32, sz = c.c_void_p, c.c_int64, c.c_uint64, c.c_float, c.c_int, c.c_size_t
+    lib.gpfq_abi_version.restype = i32
+    lib.gpfq_last_error.restype = c.c_char_p
+    lib.gpfq_padded_m.restype = i64
+    lib.gpfq_padded_m.argtypes = [i64]
+    lib.gpfq_workspace_bytes.restype = sz
+    lib.gpfq_workspace_bytes.argtypes = [i64, i64, i64, i32]
+    lib.gpfq_prepare_columns_f32.restype = i32
+    lib.gpfq_prepare_columns_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, vp, vp, i64, vp]
+    lib.gpfq_quantization_f32.restype = i32
+    lib.gpfq_quantization_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, i64, i64, i64,
+                                          f32, i32, i32, f32, u64, u64, vp, i64, i32, i32, vp]
+    lib.gpfq_quantize_layer_f32.restype = i32
+    lib.gpfq_quantize_layer_f32.argtypes = [vp, vp, i64, vp, i64, i64, i64, i64, i32, f32, i32, i32, f32, u64, u64,
+                                            vp, vp, i32, vp, vp, sz, i32, vp]
+    lib.gpfq_quantize_groups_prepared_f32.restype = i32
+    lib.gpfq_quantize_groups_prepared_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, i32, i32,
+                                                      f32, u64, u64, vp, i32, i32, vp]
+    lib.gpfq_quantizer_f32.restype = i32
+    lib.gpfq_quantizer_f32.argtypes = [i32, f32, vp, i64, i32, f32, vp, vp, vp, vp]
+    lib.gpfq_row_absmax_f32.restype = i32
+    lib.gpfq_row_absmax_f32.argtypes = [vp, i64, i64, i64, vp, vp]
+    lib.gpfq_describe_plan.restype = i32
+    lib.gpfq_describe_plan.argtypes = [i64, i64, i64, i32, i32, c.c_char_p, sz]
+    if lib.gpfq_abi_version() != 1:
+        raise ImportError("libgpfq_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise GpfqError("gpfq error %d: %s" % (rc, lib.gpfq_last_error().decode()))
+
+
+def require_gpu_tensor(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GpfqError("%s must be a tensor on the MI355X (cuda) device; this package has no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise GpfqError("%s must be float32" % name)
+
+
+def current_stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def describe_plan(N, d_g, m, groups=1, plan=PLAN_AUTO):
+    buf = ctypes.create_string_buffer(256)
+    rc = lib.gpfq_describe_plan(N, d_g, m, groups, plan, buf, 256)
+    if rc < 0:
+        check(rc)
+    return buf.value.decode()

@@ -1,0 +1,200 @@
+"""QuantizeNeuralNet -- the layer-by-layer driver with the reference's call surface
+(reference: src/quantize_neural_net.py).  `main.py` of the reference does
+
+    quantizer = QuantizeNeuralNet(model, name, batch_size, train_loader, mlp_bits=..., cnn_bits=..., ...)
+    quantized_model = quantizer.quantize_network()                       (main.py:105-121)
+
+and that works unchanged against this class.  Per layer it captures the input of the layer in the analog
+and in the partially quantized network (quantize_neural_net.py:217-274), flattens conv kernels to rows
+(:176) and hands the layer to StepAlgorithm._quantize_layer (:150, :180), which runs on the MI355X.
+"""
+import copy
+import gc
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .step_algorithm import StepAlgorithm
+from .utils import InterruptException, extract_layers
+
+LINEAR_MODULE_TYPE = nn.Linear
+CONV2D_MODULE_TYPE = nn.Conv2d
+
+RESULT_LOGGING_DIR = 'result_logging'
+LAYER_LOGGING = False
+
+
+class QuantizeNeuralNet:
+    '''Quantizes a network layer by layer with GPFQ.
+
+    Public attributes kept from the reference (quantize_neural_net.py:81-114): analog_network,
+    quantized_network, analog_network_layers, quantized_network_layers, mlp_boundary_idx,
+    cnn_boundary_idx, mlp_alphabet_step_size, cnn_alphabet_step_size, ...
+    '''
+
+    def __init__(self,
+                 network_to_quantize, network_name, batch_size, data_loader,
+                 mlp_bits, cnn_bits,
+                 ignore_layers,
+                 mlp_alphabet_scalar, cnn_alphabet_scalar,
+                 mlp_percentile, cnn_percentile,
+                 reg, lamb, retain_rate, stochastic_quantization, device):
+        self.network_name = network_name
+        self.analog_network = network_to_quantize
+        self.batch_size = batch_size
+        self.data_loader_iter = iter(data_loader)
+
+        # symmetric alphabet {-K..K}*step with K = 2^(bits-1)   (quantize_neural_net.py:87-88)
+        self.mlp_bits, self.cnn_bits = mlp_bits, cnn_bits
+        self.mlp_boundary_idx = 2 ** (mlp_bits - 1)
+        self.cnn_boundary_idx = 2 ** (cnn_bits - 1)
+        self.mlp_alphabet_scalar = mlp_alphabet_scalar
+        self.mlp_alphabet_step_size = mlp_alphabet_scalar / self.mlp_boundary_idx      # :92
+        self.cnn_alphabet_step_size = cnn_alphabet_scalar / self.cnn_boundary_idx      # :93
+        self.mlp_percentile, self.cnn_percentile = mlp_percentile, cnn_percentile
+        self.ignore_layers = ignore_layers
+        self.retain_rate = retain_rate
+        self.reg, self.lamb = reg, lamb
+        self.device = device
+        self.stochastic_quantization = stochastic_quantization
+
+        self.quantized_network = copy.deepcopy(self.analog_network)
+        self.analog_network_layers = []
+        extract_layers(self.analog_network, self.analog_network_layers)
+        self.quantized_network_layers = []
+        extract_layers(self.quantized_network, self.quantized_network_layers)
+        self.layer_reports = []     # per-layer dicts (index, errors, step) -- extra, not in the reference
+
+    def quantize_network(self):
+        '''Quantize every non-ignored Linear/Conv2d layer in registration order; returns the quantized
+        nn.Module (quantize_neural_net.py:117-214).  Biases are left untouched.'''
+        todo = [i for i in range(len(self.quantized_network_layers)) if i not in self.ignore_layers]
+        print(f'Layer indices to quantize {todo}')
+        print(f'Total number of layers to quantize {len(todo)}')
+
+        for done, layer_idx in enumerate(todo):
+            gc.collect()
+            analog_in, quantized_in = self._populate_linear_layer_input(layer_idx)
+            print(f'\nQuantizing layer with index: {layer_idx}')
+            print(f'Quantization progress: {done} out of {len(todo)-1}\n')
+
+            analog_layer = self.analog_network_layers[layer_idx]
+            W = analog_layer.weight.data
+            if type(analog_layer) == LINEAR_MODULE_TYPE:
+                groups, W_shape = 1, None
+                step_size, K, pct = self.mlp_alphabet_step_size, self.mlp_boundary_idx, self.mlp_percentile
+            elif type(analog_layer) == CONV2D_MODULE_TYPE:
+                groups, W_shape = analog_layer.groups, W.shape
+                print('shape of W:', W.shape)
+                print('shape of analog_layer_input:', analog_in.shape)
+                print('shape of quantized_layer_input:', quantized_in.shape)
+                W = W.view(W.size(0), -1)           # one row per output channel, channel-major (:176)
+                step_size, K, pct = self.cnn_alphabet_step_size, self.cnn_boundary_idx, self.cnn_percentile
+            else:
+                raise TypeError(f'The layer type {type(analog_layer)} is not currently supported')
+
+            Q, quantize_error, relative_quantize_error, quantize_adder, relative_adder = \
+                StepAlgorithm._quantize_layer(W, analog_in, quantized_in, analog_in.shape[0], step_size, K, pct,
+                                              self.reg, self.lamb, groups, self.stochastic_quantization,
+                                              self.device)
+            Q = Q.float() if W_shape is None else Q.reshape(W_shape).float()
+            self.quantized_network_layers[layer_idx].weight.data = Q
+
+            print(f'The quantization error of layer {layer_idx} is {quantize_error.cpu().numpy()}.')
+            print(f'The relative quantization error of layer {layer_idx} is {relative_quantize_error.cpu().numpy()}.\n')
+            self.layer_reports.append(dict(layer=layer_idx, quantize_error=float(quantize_error),
+                                           relative_quantize_error=float(relative_quantize_error)))
+            if LAYER_LOGGING:
+                self._log_layer(layer_idx, W, Q, quantize_adder, relative_adder)
+
+            del analog_in, quantized_in
+            gc.collect()
+        return self.quantized_network
+
+    def _log_layer(self, layer_idx, W, Q, quantize_adder, relative_adder):
+        '''Optional .npy dumps of W, Q, U^T and the per-neuron relative error (quantize_neural_net.py:199-209).'''
+        os.makedirs(RESULT_LOGGING_DIR, exist_ok=True)
+        tag = (f'batch_size:{self.batch_size}_model_name:{self.network_name}_bits:{self.mlp_bits}'
+               f'_scalar:{self.mlp_alphabet_scalar}_stochastic:{self.stochastic_quantization}_layer:{layer_idx}')
+        for suffix, val in (('ori', W), ('quant', Q), ('adder', quantize_adder), ('relative', relative_adder)):
+            arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else val
+            np.save(os.path.join(RESULT_LOGGING_DIR, f'{tag}_{suffix}.npy'), arr)
+
+    def _populate_linear_layer_input(self, layer_idx):
+        '''Inputs of layer `layer_idx` in the analog and in the (partially) quantized network for the NEXT
+        batch of the loader (quantize_neural_net.py:217-274).  Both forwards are cut at the hooked layer.
+        Returns (analog_layer_input, quantized_layer_input), each (m, features).'''
+        raw_input_data, _ = next(self.data_loader_iter)
+        analog_layer = self.analog_network_layers[layer_idx]
+        if type(analog_layer) == LINEAR_MODULE_TYPE:
+            save_input = SaveInputMLP()
+        elif type(analog_layer) == CONV2D_MODULE_TYPE:
+            save_input = SaveInputConv2d(kernel_size=analog_layer.kernel_size, dilation=analog_layer.dilation,
+                                         padding=analog_layer.padding, stride=analog_layer.stride,
+                                         groups=analog_layer.groups, retain_rate=self.retain_rate)
+        else:
+            raise TypeError(f'The layer type {type(analog_layer)} is not currently supported')
+
+        # the SAME hook object sees the analog net first, then the quantized net (shared patch sample)
+        with torch.no_grad():
+            for net, layer in ((self.analog_network, analog_layer),
+                               (self.quantized_network, self.quantized_network_layers[layer_idx])):
+                handle = layer.register_forward_hook(save_input)
+                try:
+                    net(raw_input_data.to(self.device))
+                except InterruptException:
+                    pass
+                finally:
+                    handle.remove()
+        del raw_input_data
+        gc.collect()
+        return (save_input.inputs[0], save_input.inputs[1])
+
+
+class SaveInputMLP:
+    '''Forward hook that records the input of a Linear layer and aborts the forward
+    (quantize_neural_net.py:277-292).'''
+
+    def __init__(self):
+        self.inputs = []
+
+    def __call__(self, module, module_in, module_out):
+        if len(module_in) != 1:
+            raise TypeError('The number of input layer is not equal to one!')
+        self.inputs.append(module_in[0])
+        raise InterruptException
+
+
+class SaveInputConv2d:
+    '''Forward hook for Conv2d layers (quantize_neural_net.py:295-350): the input feature map is cut into
+    kernel-sized patches on a grid whose stride is the KERNEL SIZE (the layer's own stride is not used,
+    :320), every patch becomes a row (channel-major, then kh, kw), and per image int(p*L + 1) patches
+    (all L if p == 1) are drawn with replacement; the draw of the first call is reused for the second.'''
+
+    def __init__(self, kernel_size, dilation, padding, stride, groups, retain_rate):
+        self.p = retain_rate
+        self.kernel_size, self.dilation, self.padding = kernel_size, dilation, padding
+        self.groups = groups
+        self.inputs = []
+        self.call_count = 0
+        self.rand_indices = None
+
+    def __call__(self, module, module_in, module_out):
+        if len(module_in) != 1:
+            raise TypeError('The number of input layer is not equal to one!')
+        x = module_in[0]                                               # (B, C, H, W)
+        cols = F.unfold(x, self.kernel_size, dilation=self.dilation, padding=self.padding,
+                        stride=self.kernel_size)                       # (B, C*kh*kw, L)
+        B, L = cols.shape[0], cols.shape[-1]
+        if self.call_count == 0:
+            keep = int(self.p * L + 1 if self.p != 1 else self.p * L)
+            # same generator consumption as np.random.choice(np.arange(L*i, L*(i+1)), size=keep), i = 0..B-1
+            self.rand_indices = np.concatenate([L * i + np.random.choice(L, size=keep) for i in range(B)])
+        self.call_count += 1
+        rows = cols.transpose(1, 2).reshape(B * L, -1)                 # (B*L, C*kh*kw)
+        sel = torch.as_tensor(self.rand_indices, device=rows.device, dtype=torch.long)
+        self.inputs.append(rows.index_select(0, sel))
+        raise InterruptException

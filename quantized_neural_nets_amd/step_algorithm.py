@@ -1,0 +1,282 @@
+"""StepAlgorithm -- MI355X counterpart of the reference's operator surface (src/step_algorithm.py).
+
+Same names, argument order and return values as the reference class (it is used unbound, without an
+instance: quantize_neural_net.py:150, :180), so the driver and user code call it unchanged:
+
+    StepAlgorithm._quantize_layer(W, analog_layer_input, quantized_layer_input, m, step_size, boundary_idx,
+                                  percentile, reg, lamb, groups, stochastic_quantization, device)
+        -> (Q, quantize_error, relative_quantize_error, quantize_adder, relative_adder)   step_algorithm.py:151-249
+    StepAlgorithm._quantization(W, Q, U, analog_layer_input, quantized_layer_input, quantizer,
+                                step_size, boundary_idx, lamb) -> None (in place on Q, U)      step_algorithm.py:107-148
+    StepAlgorithm._msq / _soft_thresholding_msq / _hard_thresholding_msq / _stochastic_msq     step_algorithm.py:7-104
+
+All arithmetic of the loop runs in the HIP kernels behind include/gpfq.h (ctypes, _lib.py).  torch is used
+for device memory, the current stream, the alphabet-radius statistic (:191) and the error-metric GEMM
+(:216-219).  Tensors must live on the GPU; there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import dist as _dist
+
+_MODE_BY_NAME = {"_msq": _lib.MODE_MSQ, "_soft_thresholding_msq": _lib.MODE_SOFT,
+                 "_hard_thresholding_msq": _lib.MODE_HARD, "_stochastic_msq": _lib.MODE_STOCHASTIC}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _rows_view(t, name):
+    """Row-major 2-D view with unit column stride (copies only if the view cannot be expressed with a
+    leading dimension).  Returns (tensor, leading dimension in elements)."""
+    _lib.require_gpu_tensor(t, name)
+    if t.dim() != 2:
+        raise _lib.GpfqError("%s must be 2-D" % name)
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t, max(ld, t.shape[1], 1)
+
+
+def _idx_dtype(K):
+    return (torch.int8, 1) if K <= 126 else (torch.int16, 2)
+
+
+def _elementwise(mode, step_size, x, boundary_idx, lamb, uniform=None):
+    _lib.require_gpu_tensor(x, "x")
+    xc = x.contiguous()
+    out = torch.empty_like(xc)
+    un = None
+    if uniform is not None:
+        un = uniform.contiguous()
+    _lib.check(_lib.lib.gpfq_quantizer_f32(mode, float(step_size), _ptr(xc), xc.numel(), int(boundary_idx),
+                                           float(lamb if lamb is not None else 0.0),
+                                           _ptr(un) if un is not None else None, _ptr(out), None,
+                                           _lib.current_stream_ptr(x.device)))
+    return out.view(x.shape)
+
+
+class StepAlgorithm:
+
+    # seed of the counter-based generator used by the stochastic quantizer inside the loop kernels;
+    # advanced by every stochastic layer so that layers draw independent streams.
+    stochastic_seed = 0
+    # kernel family override for experiments / tests (see include/gpfq.h GPFQ_PLAN_*)
+    plan = _lib.PLAN_AUTO
+    # optional callable(tag, shape) invoked around the column preparation and the loop kernel (bench.py)
+    event_hook = None
+
+    def _stochastic_msq(step_size, x, boundary_idx, lamb):
+        '''Stochastic rounding to the alphabet, clipped to boundary_idx (step_algorithm.py:7-35).
+        Like the reference it overwrites and returns x.  The Bernoulli draws come from torch's CUDA
+        generator (torch.rand), not from the reference's CPU stream: distribution parity only.'''
+        un = torch.rand(x.shape, device=x.device, dtype=torch.float32)
+        x.copy_(_elementwise(_lib.MODE_STOCHASTIC, step_size, x, boundary_idx, lamb, un))
+        return x
+
+    def _msq(step_size, x, boundary_idx, lamb):
+        '''Nearest element of the uniform symmetric alphabet (step_algorithm.py:38-56).'''
+        return _elementwise(_lib.MODE_MSQ, step_size, x, boundary_idx, lamb)
+
+    def _hard_thresholding_msq(step_size, x, boundary_idx, lamb):
+        '''Hard-thresholding quantizer, reg == 'L0' (step_algorithm.py:59-81).'''
+        return _elementwise(_lib.MODE_HARD, step_size, x, boundary_idx, lamb)
+
+    def _soft_thresholding_msq(step_size, x, boundary_idx, lamb):
+        '''Soft-thresholding quantizer, reg == 'L1' (step_algorithm.py:84-104).'''
+        return _elementwise(_lib.MODE_SOFT, step_size, x, boundary_idx, lamb)
+
+    def _quantization(W, Q, U, analog_layer_input, quantized_layer_input, quantizer,
+                      step_size, boundary_idx, lamb):
+        '''The GPFQ loop over the columns of one group, in place on Q and U (step_algorithm.py:107-148).
+
+        W, Q : (N, d) weights / quantized weights        U : (N, m) residual, read and updated
+        analog_layer_input, quantized_layer_input : (m, d), may be strided views (:236)
+        quantizer : one of the four StepAlgorithm quantizers (selects the fused epilogue)
+        '''
+        mode = _MODE_BY_NAME.get(getattr(quantizer, "__name__", None))
+        if mode is None:
+            raise _lib.GpfqError("quantizer must be one of StepAlgorithm._msq/_soft_thresholding_msq/"
+                                 "_hard_thresholding_msq/_stochastic_msq")
+        Wv, ldw = _rows_view(W, "W")
+        A, lda = _rows_view(analog_layer_input, "analog_layer_input")
+        X, ldx = _rows_view(quantized_layer_input, "quantized_layer_input")
+        N, d = Wv.shape
+        m = A.shape[0]
+        if A.shape != (m, d) or X.shape != (m, d) or tuple(Q.shape) != (N, d) or tuple(U.shape) != (N, m):
+            raise _lib.GpfqError("shape mismatch: W %s Q %s U %s A %s X %s" % (
+                tuple(W.shape), tuple(Q.shape), tuple(U.shape), tuple(A.shape), tuple(X.shape)))
+        Qv, ldq = _rows_view(Q, "Q")
+        Uv, ldu = _rows_view(U, "U")
+        dev = W.device
+        mp = _lib.lib.gpfq_padded_m(m)
+        AT = torch.empty((max(d, 1), mp), device=dev, dtype=torch.float32)
+        XT = torch.empty((max(d, 1), mp), device=dev, dtype=torch.float32)
+        nrm2 = torch.empty((max(d, 1),), device=dev, dtype=torch.float32)
+        st = _lib.current_stream_ptr(dev)
+        _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A), lda, _ptr(X), ldx, m, d, _ptr(AT), _ptr(XT),
+                                                     _ptr(nrm2), mp, st))
+        seed = StepAlgorithm.stochastic_seed
+        if mode == _lib.MODE_STOCHASTIC:
+            StepAlgorithm.stochastic_seed += 1
+        _lib.check(_lib.lib.gpfq_quantization_f32(
+            _ptr(Wv), ldw, _ptr(Qv), ldq, _ptr(Uv), ldu, 1, _ptr(AT), _ptr(XT), _ptr(nrm2), N, d, m, mp,
+            float(step_size), int(boundary_idx), mode, float(lamb if lamb is not None else 0.0), seed, 0,
+            None, 0, 1, StepAlgorithm.plan, st))
+        if Qv.data_ptr() != Q.data_ptr():
+            Q.copy_(Qv)
+        if Uv.data_ptr() != U.data_ptr():
+            U.copy_(Uv)
+
+    def _alphabet_step(W, step_size, boundary_idx, percentile, reg, lamb):
+        '''rad = mean over neurons of the per-neuron |w| quantile; step = step_size*rad (- lamb/K for L0)
+        (step_algorithm.py:191-192).  The per-row statistic is computed on the GPU; the mean of the N row
+        values and the scalar arithmetic use the same torch CPU ops as the reference's CPU path, so the
+        fp32 step is bit-identical to it.  Returns a 0-dim fp32 CPU tensor.'''
+        N, d = W.shape
+        if percentile == 1:
+            Wv, ldw = _rows_view(W, "W")
+            rowstat = torch.empty((N,), device=W.device, dtype=torch.float32)
+            _lib.check(_lib.lib.gpfq_row_absmax_f32(_ptr(Wv), ldw, N, d, _ptr(rowstat),
+                                                    _lib.current_stream_ptr(W.device)))
+        else:
+            rowstat = torch.quantile(torch.abs(W), percentile, axis=1)
+        rad = rowstat.cpu().mean()
+        return step_size * rad - lamb / boundary_idx if reg == 'L0' else step_size * rad
+
+    def _quantize_layer_ex(W, analog_layer_input, quantized_layer_input, m, step_size, boundary_idx, percentile,
+                           reg, lamb, groups, stochastic_quantization, device, compute_errors=True,
+                           step_override=None):
+        '''_quantize_layer with the extra outputs the native path produces.  Returns a dict with
+        Q (N, d_g) fp32, idx (N, d_g) int8/int16 alphabet indices, U (local rows of the residual), step,
+        and, if compute_errors, quantize_error / relative_quantize_error / quantize_adder / relative_adder.
+        When neuron sharding is enabled (dist.enable) W's rows are split over the ranks, the index shards are
+        all-gathered (one RCCL all_gather per layer) and Q is rebuilt locally; U stays sharded.'''
+        _lib.require_gpu_tensor(W, "W")
+        _lib.require_gpu_tensor(analog_layer_input, "analog_layer_input")
+        _lib.require_gpu_tensor(quantized_layer_input, "quantized_layer_input")
+        if W.dim() != 2:
+            raise _lib.GpfqError("W must be (N, d)")
+        W = W.contiguous()
+        N, dg = W.shape
+        A, lda = _rows_view(analog_layer_input, "analog_layer_input")
+        X, ldx = _rows_view(quantized_layer_input, "quantized_layer_input")
+        mm = A.shape[0]
+        if A.shape != (mm, groups * dg) or X.shape != A.shape:
+            raise _lib.GpfqError("layer inputs must be (m, groups*d): got %s / %s for W %s groups %d" % (
+                tuple(A.shape), tuple(X.shape), tuple(W.shape), groups))
+        if N % groups != 0:
+            raise _lib.GpfqError("out_channels must be divisible by groups")
+        K = int(boundary_idx)
+        lamb_f = float(lamb if lamb is not None else 0.0)
+        if step_override is not None:
+            step_t = torch.tensor(step_override, dtype=torch.float32)
+        else:
+            step_t = StepAlgorithm._alphabet_step(W, step_size, K, percentile, reg, lamb_f)
+        step = float(step_t)
+        if reg == 'L1':
+            mode = _lib.MODE_SOFT
+        elif reg == 'L0':
+            mode = _lib.MODE_HARD
+        else:
+            mode = _lib.MODE_STOCHASTIC if stochastic_quantization else _lib.MODE_MSQ
+        seed = StepAlgorithm.stochastic_seed
+        if mode == _lib.MODE_STOCHASTIC:
+            StepAlgorithm.stochastic_seed += 1
+        idx_dtype, idx_bytes = _idx_dtype(K)
+        dev = W.device
+        st = _lib.current_stream_ptr(dev)
+
+        def run_rows(W_loc, groups_loc, A_loc, lda_loc, X_loc, ldx_loc, row_id0):
+            """all groups of a (sub)layer in one launch; returns Q, idx, U for those rows"""
+            Nl = W_loc.shape[0]
+            Q = torch.empty((Nl, dg), device=dev, dtype=torch.float32)
+            idx = torch.empty((Nl, dg), device=dev, dtype=idx_dtype)
+            U = torch.empty((Nl, mm), device=dev, dtype=torch.float32)
+            if Nl == 0 or dg == 0:
+                Q.zero_(); idx.zero_(); U.zero_()
+                return Q, idx, U
+            # the two halves of gpfq_quantize_layer_f32, called separately so that a profiler hook can
+            # bracket the column preparation and the loop kernel with events on the current stream
+            D = groups_loc * dg
+            mp = _lib.lib.gpfq_padded_m(mm)
+            AT = torch.empty((D, mp), device=dev, dtype=torch.float32)
+            XT = torch.empty((D, mp), device=dev, dtype=torch.float32)
+            nrm2 = torch.empty((D,), device=dev, dtype=torch.float32)
+            hook = StepAlgorithm.event_hook
+            if hook:
+                hook("prepare_begin", (Nl, dg, mm, groups_loc))
+            _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A_loc), lda_loc, _ptr(X_loc), ldx_loc, mm, D,
+                                                         _ptr(AT), _ptr(XT), _ptr(nrm2), mp, st))
+            if hook:
+                hook("loop_begin", (Nl, dg, mm, groups_loc))
+            _lib.check(_lib.lib.gpfq_quantize_groups_prepared_f32(
+                _ptr(W_loc), _ptr(Q), _ptr(U), _ptr(AT), _ptr(XT), _ptr(nrm2), Nl, dg, mm, mp, groups_loc,
+                step, K, mode, lamb_f, seed, int(row_id0), _ptr(idx), idx_bytes, StepAlgorithm.plan, st))
+            if hook:
+                hook("loop_end", (Nl, dg, mm, groups_loc))
+            return Q, idx, U
+
+        shard = _dist.active()
+        if shard is None:
+            Q, idx, U = run_rows(W, groups, A, lda, X, ldx, 0)
+            rows = None
+        else:
+            Q, idx, U, rows = _dist.quantize_sharded(shard, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb_f,
+                                                     idx_dtype, run_rows)
+        out = dict(Q=Q, idx=idx, U=U, step=step_t, rows=rows)
+        if compute_errors:
+            out.update(StepAlgorithm._error_metrics(W, A, U, groups, rows, shard))
+        return out
+
+    def _error_metrics(W, A, U, groups, rows, shard):
+        '''step_algorithm.py:216-219 (groups == 1) and :239-243 (mean over groups of per-group norms).
+        A @ W.T is one MFMA GEMM (torch.matmul -> hipBLASLt), computed once instead of twice.'''
+        N, dg = W.shape
+        mm = A.shape[0]
+        if shard is not None:
+            return _dist.sharded_error_metrics(shard, W, A, U, groups, rows)
+        if groups == 1:
+            quantize_adder = U.T
+            AW = A @ W.T
+            relative_adder = torch.linalg.norm(quantize_adder, axis=0) / (torch.linalg.norm(AW, axis=0) + 1e-5)
+            quantize_error = torch.linalg.norm(quantize_adder, ord='fro')
+            relative_quantize_error = quantize_error / torch.linalg.norm(AW, ord='fro')
+        else:
+            Ng = N // groups
+            U3 = U.view(groups, Ng, mm)
+            un = torch.linalg.norm(U3.reshape(groups, -1), dim=1)
+            A3 = A.reshape(mm, groups, dg).permute(1, 0, 2)                # (g, m, d_g)
+            AW = torch.bmm(A3, W.view(groups, Ng, dg).transpose(1, 2))      # (g, m, Ng)
+            an = torch.linalg.norm(AW.reshape(groups, -1), dim=1)
+            quantize_error = un.sum() / groups
+            relative_quantize_error = (un / an).sum() / groups
+            quantize_adder = None
+            relative_adder = None
+        return dict(quantize_error=quantize_error, relative_quantize_error=relative_quantize_error,
+                    quantize_adder=quantize_adder, relative_adder=relative_adder)
+
+    def _quantize_layer(W, analog_layer_input, quantized_layer_input, m,
+                        step_size, boundary_idx, percentile,
+                        reg, lamb, groups, stochastic_quantization, device):
+        '''Quantize one layer, all output neurons in parallel (step_algorithm.py:151-249).
+
+        W : (N, d_g) layer weights (conv kernels already flattened by the caller)
+        analog_layer_input, quantized_layer_input : (m, groups*d_g)
+        step_size : alphabet step before scaling by the layer radius; boundary_idx : K = 2**(bits-1)
+        Returns (Q, quantize_error, relative_quantize_error, quantize_adder, relative_adder) like the reference.
+        '''
+        print(f'The number of groups: {groups}\n')
+        r = StepAlgorithm._quantize_layer_ex(W, analog_layer_input, quantized_layer_input, m, step_size,
+                                             boundary_idx, percentile, reg, lamb, groups,
+                                             stochastic_quantization, device)
+        StepAlgorithm.last_result = r
+        return r["Q"], r["quantize_error"], r["relative_quantize_error"], r["quantize_adder"], r["relative_adder"]
+
+
+StepAlgorithm.last_result = None

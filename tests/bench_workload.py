@@ -1,0 +1,50 @@
+"""The benchmark workload (BASELINE.json / SURVEY.md 8d): layer shapes and synthetic inputs.
+Shared by bench.py and the full-size GPU tests."""
+import math
+
+import torch
+
+# ResNet-50, 224x224 input, calibration batch B, retain_rate 0.25: m = B * int(0.25*L + 1) with
+# L = (floor((H + 2p - (k-1) - 1)/k) + 1)^2 (unfold stride = kernel size, quantize_neural_net.py:320)
+def conv_m(B, H, k, pad, retain=0.25):
+    L = ((H + 2 * pad - (k - 1) - 1) // k + 1) ** 2
+    return B * int(retain * L + 1 if retain != 1 else L)
+
+
+def resnet50_3x3_layers(B=1024):
+    """[(name, N, d, m)] for the sixteen 3x3 conv2 layers."""
+    layers = []
+    spec = [("layer1", 64, 3, 56, 56), ("layer2", 128, 4, 56, 28), ("layer3", 256, 6, 28, 14), ("layer4", 512, 3, 14, 7)]
+    for name, planes, blocks, h_first, h_rest in spec:
+        for b in range(blocks):
+            H = h_first if b == 0 else h_rest       # conv2 of block 0 sees the pre-stride map
+            layers.append(("%s.%d.conv2" % (name, b), planes, planes * 9, conv_m(B, H, 3, 1)))
+    return layers
+
+
+def algorithmic_bytes(N, d, m, groups=1):
+    """per greedy step of one group 8*N_g*m + 8*m + 8*N_g bytes; per layer groups*d_g times that."""
+    Ng = N // groups
+    return groups * d * (8 * Ng * m + 8 * m + 8 * Ng)
+
+
+def synthetic_layer(N, d, m, seed, first_layer=False, d_limit=None):
+    """W = randn*sqrt(2/d); A = relu(pre); X = relu(pre + 0.05 randn); every 97th column of X zero.
+    CPU generator so that every path sees identical bits.  d_limit keeps only the first columns."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    dd = d if d_limit is None else min(d, d_limit)
+    W = torch.randn(N, dd, generator=g) * math.sqrt(2.0 / d)
+    pre = torch.randn(m, dd, generator=g)
+    if first_layer:
+        A = pre
+        X = pre.clone()
+    else:
+        A = torch.relu(pre)
+        X = torch.relu(pre + 0.05 * torch.randn(m, dd, generator=g))
+    X[:, ::97] = 0.0
+    return W, A, X
+
+
+def layer_step(W, scalar=1.16, K=8):
+    """alphabet step for percentile 1: (scalar/K) * mean(rowmax |W|)  (step_algorithm.py:191-192)"""
+    return float((scalar / K) * W.abs().max(dim=1).values.mean())

@@ -1,0 +1,54 @@
+"""Full-size checks on the MI355X at BASELINE.json's layer shapes (ResNet-50 3x3 convs, calibration batch
+1024), through size-independent properties, plus one full-size layer against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import bench_workload as bw
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _layer(qnn_plan, shape, seed, rows=None, d_limit=None):
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    N, d, m = shape
+    W, A, X = bw.synthetic_layer(N, d, m, seed, first_layer=False, d_limit=d_limit)
+    Wd = W.to(DEV)
+    if rows is not None:
+        Wd = Wd[rows[0]:rows[1]].contiguous()
+    SA.plan = qnn_plan
+    try:
+        r = SA._quantize_layer_ex(Wd, A.to(DEV), X.to(DEV), m, 1.16 / 8, 8, 1, None, 0.1, 1, False,
+                                  torch.device(DEV), step_override=bw.layer_step(W))
+    finally:
+        SA.plan = 0
+    torch.cuda.synchronize()
+    return W, A, X, r
+
+
+@pytest.mark.parametrize("shape", [(512, 4608, 3072), (256, 2304, 7168)])
+def test_full_size_layer_row_subset_and_plans_agree(shape):
+    """(a) quantizing rows [a, b) alone equals the slice of the full result (the neuron-shard property);
+    (b) the resident and the streaming kernel families agree bit for bit; (c) |idx| <= K."""
+    W, A, X, full = _layer(0, shape, 1234 + 40)
+    _, _, _, part = _layer(0, shape, 1234 + 40, rows=(37, 101))
+    assert torch.equal(part["idx"], full["idx"][37:101])
+    assert torch.equal(part["U"], full["U"][37:101])
+    _, _, _, st = _layer(1, shape, 1234 + 40)
+    assert torch.equal(st["idx"], full["idx"]) and torch.equal(st["U"], full["U"]) and torch.equal(st["Q"], full["Q"])
+    assert int(full["idx"].abs().max()) <= 8
+    # residual identity: U == A-projected error, i.e. U = W A^T - Q X^T up to fp32 accumulation
+    Wd, Ad, Xd = W.to(DEV).double(), A.to(DEV).double(), X.to(DEV).double()
+    ref = Wd @ Ad.T - full["Q"].double() @ Xd.T
+    assert (full["U"].double() - ref).abs().max().item() < 5e-3
+
+
+def test_full_size_layer_against_oracle(oracle_mod):
+    """ResNet-50 layer4.{1,2}.conv2 at batch 1024 (N=512, d=4608, m=3072), first 512 columns bit-exact vs the
+    CPU oracle (the oracle needs ~10 s for this many columns)."""
+    shape = (512, 4608, 3072)
+    W, A, X, r = _layer(0, shape, 1234 + 41, d_limit=512)
+    Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
+    assert np.array_equal(r["U"].cpu().numpy(), U)

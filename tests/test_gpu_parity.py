@@ -1,0 +1,185 @@
+"""Parity of the HIP path (through the C ABI, via the Python mirror of the reference's operator surface)
+against (1) the golden vectors made from the imported reference and (2) the CPU oracle.
+
+Bar: alphabet indices bit-exact vs the reference fixtures; residual U within 1e-5 of the reference
+(BASELINE.md 5); and, because the kernels and the oracle share one canonical reduction order, idx / Q / U
+BIT-EXACT against the oracle on any seeded input.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def qnn():
+    import quantized_neural_nets_amd as q
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return q
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _run_layer(qnn, case, W, A, X, plan=0):
+    from quantized_neural_nets_amd import StepAlgorithm
+    K = 2 ** (case["bits"] - 1)
+    StepAlgorithm.plan = plan
+    try:
+        r = StepAlgorithm._quantize_layer_ex(_t(W), _t(A), _t(X), A.shape[0], case["scalar"] / K, K,
+                                             case["percentile"], case["reg"], case["lamb"], case["groups"], False,
+                                             torch.device(DEV))
+    finally:
+        StepAlgorithm.plan = 0
+    torch.cuda.synchronize()
+    return r
+
+
+def test_quantizer_kernels_match_reference_vectors(qnn):
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g1_quantizers.npz"))
+    cfgs = json.loads(str(fx["meta"]))["configs"]
+    for ci, c in enumerate(cfgs):
+        x = _t(fx["x_%d" % ci])
+        for name, fn in (("msq", SA._msq), ("soft", SA._soft_thresholding_msq), ("hard", SA._hard_thresholding_msq)):
+            out = fn(c["step"], x, c["K"], c["lamb"]).cpu().numpy()
+            ref = fx["%s_%d" % (name, ci)]
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (name, ci)
+
+
+def test_stochastic_quantizer_is_unbiased(qnn):
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    x = torch.full((200000,), 0.3, device=DEV)
+    q = SA._stochastic_msq(0.25, x.clone(), 4, 0.0)
+    assert set(torch.unique(q).cpu().tolist()) == {0.25, 0.5}
+    assert abs(q.mean().item() - 0.3) < 2e-3
+    q = SA._stochastic_msq(0.25, torch.tensor([5.0, -5.0], device=DEV), 4, 0.0)
+    assert q.cpu().tolist() == [1.0, -1.0]
+
+
+@pytest.mark.parametrize("name", gi.available_cases())
+@pytest.mark.parametrize("plan", [0, 1])
+def test_layer_against_reference_and_oracle(qnn, oracle_mod, name, plan):
+    case, (W, A, X), fx, meta = gi.load_case(name)
+    r = _run_layer(qnn, case, W, A, X, plan)
+    K = 2 ** (case["bits"] - 1)
+    assert np.float32(float(r["step"])) == fx["step"]
+    idx = r["idx"].cpu().numpy()
+    Q = r["Q"].cpu().numpy()
+    U = r["U"].cpu().numpy()
+    # (1) the reference's own outputs
+    assert np.array_equal(idx.astype(np.int16), fx["idx"]), "alphabet indices differ from the reference"
+    assert np.array_equal(Q, fx["Q"])
+    assert np.abs(U - fx["U"]).max() <= 1e-5
+    assert abs(float(r["quantize_error"]) - float(fx["quantize_error"])) <= 1e-4 * float(fx["quantize_error"])
+    assert abs(float(r["relative_quantize_error"]) - float(fx["relative_quantize_error"])) <= 1e-4 * float(
+        fx["relative_quantize_error"])
+    if case["groups"] == 1:
+        assert np.allclose(r["relative_adder"].cpu().numpy(), fx["relative_adder"], rtol=1e-4, atol=1e-6)
+        assert tuple(r["quantize_adder"].shape) == (A.shape[0], W.shape[0])
+    else:
+        assert r["quantize_adder"] is None and r["relative_adder"] is None
+    # (2) the oracle, bit for bit
+    o = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"],
+                                  case["groups"])
+    assert np.array_equal(idx.astype(np.int16), o["idx"])
+    assert np.array_equal(Q.view(np.uint32), o["Q"].view(np.uint32))
+    assert np.array_equal(U, o["U"])
+
+
+RANDOM_SHAPES = [
+    # N, d, m, groups, mode, bits
+    (48, 40, 7168, 1, "msq", 4),      # resident, 7 waves
+    (20, 24, 16384, 1, "soft", 2),    # resident, 16 waves (largest)
+    (12, 30, 17000, 1, "msq", 4),     # stream, 17 segments, ragged tail
+    (5, 12, 70000, 1, "hard", 3),     # stream, > 64 segments (second-level lanes wrap)
+    (1024, 16, 300, 1, "msq", 4),     # many rows, single segment
+    (1030, 8, 2100, 1, "msq", 4),     # stream RT=4 with a ragged last row tile (forced below)
+    (64, 9, 1500, 64, "msq", 4),      # depthwise
+    (36, 20, 4000, 3, "soft", 4),     # grouped
+]
+
+
+@pytest.mark.parametrize("shape", RANDOM_SHAPES)
+@pytest.mark.parametrize("plan", [0, 1])
+def test_random_shapes_bit_exact_vs_oracle(qnn, oracle_mod, shape, plan):
+    N, d, m, groups, mode, bits = shape
+    reg = {"msq": None, "soft": "L1", "hard": "L0"}[mode]
+    case = dict(name="rnd_%s" % "_".join(map(str, shape)), N=N, d=d, m=m, bits=bits, scalar=1.16, percentile=1.0,
+                reg=reg, lamb=0.02, groups=groups, first_layer=False, zero_every=5, seed=3)
+    W, A, X = gi.make_inputs(case)
+    r = _run_layer(qnn, case, W, A, X, plan)
+    K = 2 ** (bits - 1)
+    o = oracle_mod.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
+    assert np.float32(float(r["step"])) == o["step"]
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
+    assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+
+
+def test_quantization_in_place_with_initial_residual_and_views(qnn, oracle_mod):
+    """StepAlgorithm._quantization mirrors step_algorithm.py:107-148: in place on Q and U, U may be non-zero,
+    inputs may be strided group views (:236)."""
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    case, (W, A, X), fx, _ = gi.load_case("g4_groups2")
+    step = float(fx["step"])
+    g, N, d, m = 2, 16, 36, 120
+    Wt, At, Xt = _t(W), _t(A), _t(X)
+    Q = torch.zeros_like(Wt)
+    U = torch.zeros(N, m, device=DEV)
+    W3, Q3, U3 = Wt.view(g, -1, d), Q.view(g, -1, d), U.view(g, -1, m)
+    A3, X3 = At.view(m, g, -1), Xt.view(m, g, -1)
+    for i in range(g):
+        SA._quantization(W3[i], Q3[i], U3[i], A3[:, i, :], X3[:, i, :], SA._msq, step, 8, 0.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(Q.cpu().numpy(), fx["Q"]) and np.abs(U.cpu().numpy() - fx["U"]).max() <= 1e-5
+    # split the column range in two calls, carrying U
+    case, (W, A, X), fx, _ = gi.load_case("g2_16x64x96_msq_b4")
+    Wt, At, Xt = _t(W), _t(A), _t(X)
+    Q = torch.zeros_like(Wt)
+    U = torch.zeros(16, 96, device=DEV)
+    k = 23
+    SA._quantization(Wt[:, :k], Q[:, :k], U, At[:, :k], Xt[:, :k], SA._msq, float(fx["step"]), 8, 0.0)
+    SA._quantization(Wt[:, k:], Q[:, k:], U, At[:, k:], Xt[:, k:], SA._msq, float(fx["step"]), 8, 0.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(Q.cpu().numpy(), fx["Q"]) and np.abs(U.cpu().numpy() - fx["U"]).max() <= 1e-5
+
+
+def test_stochastic_loop_matches_oracle_bitwise(qnn, oracle_mod):
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    case, (W, A, X), fx, _ = gi.load_case("g2_16x64x96_msq_b4")
+    SA.stochastic_seed = 77
+    r = SA._quantize_layer_ex(_t(W), _t(A), _t(X), 96, 1.16 / 8, 8, 1.0, None, 0.0, 1, True, torch.device(DEV))
+    torch.cuda.synchronize()
+    Q, idx, U = oracle_mod.quantization(W, A, X, float(r["step"]), 8, mode=oracle_mod.MODE_STOCHASTIC, seed=77)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
+    assert np.array_equal(r["U"].cpu().numpy(), U)
+    assert not np.array_equal(idx, fx["idx"])           # it really is stochastic
+    assert np.abs(idx).max() <= 8
+
+
+def test_cpu_tensors_are_refused(qnn):
+    from quantized_neural_nets_amd import StepAlgorithm as SA, _lib
+    W = torch.zeros(4, 4)
+    with pytest.raises(_lib.GpfqError):
+        SA._quantize_layer(W, torch.zeros(8, 4), torch.zeros(8, 4), 8, 0.1, 8, 1, None, 0.1, 1, False, "cpu")
+
+
+def test_c_abi_argument_errors(qnn):
+    from quantized_neural_nets_amd import _lib
+    import ctypes
+    x = torch.zeros(8, device=DEV)
+    rc = _lib.lib.gpfq_quantizer_f32(9, 0.1, ctypes.c_void_p(x.data_ptr()), 8, 4, 0.0, None,
+                                     ctypes.c_void_p(x.data_ptr()), None, None)
+    assert rc == -1 and b"bad argument" in _lib.lib.gpfq_last_error()
+    with pytest.raises(_lib.GpfqError):
+        _lib.describe_plan(64, 9, 100000, 1, _lib.PLAN_RESIDENT)
