@@ -28,8 +28,10 @@
  *   - inside segment s, "lane" l (0..63) owns the 16 elements 1024 s + 256 c + 4 l + j (c, j = 0..3) and
  *     accumulates them in that order with a fused multiply-add chain starting from +0.0f;
  *   - the 64 lane sums are added by a balanced pairwise tree over the lane index (tree64);
- *   - segment sums are added sequentially into 64 second-level lanes (segment s goes to lane s mod 64,
- *     in increasing s), and those are added by tree64 again.
+ *   - the S segment sums are placed into P = 2^ceil(log2 S) slots, segment s at slot floor(s*P/S) (the
+ *     other slots hold +0.0f), and the slots are added by a balanced pairwise tree over the slot index.
+ *     (Any aligned power-of-two block of slots holds S/C +- 1 segments, which is what lets C workgroups
+ *     each pre-reduce a block of one row and still reproduce this order bit for bit.)
  * Zero padding is an exact no-op for every step of that definition.
  */
 #include <math.h>
@@ -130,11 +132,26 @@ static inline float tree64(float* v)
     return v[0];
 }
 
+/* second level: segment sums -> P slots -> pairwise tree */
+static float slot_tree(const float* seg, long S)
+{
+    long P = 1;
+    while (P < S) P <<= 1;
+    float* slot = (float*)malloc((size_t)P * sizeof(float));
+    for (long i = 0; i < P; ++i) slot[i] = 0.0f;
+    for (long s = 0; s < S; ++s) slot[(s * P) / S] = seg[s];
+    for (long off = 1; off < P; off <<= 1)
+        for (long l = 0; l < P; l += 2 * off) slot[l] = slot[l] + slot[l + off];
+    float r = slot[0];
+    free(slot);
+    return r;
+}
+
 /* u, x: length S*1024 (zero padded) */
 float gpfq_oracle_cdot(const float* u, const float* x, long S)
 {
-    float lane2[64];
-    for (int l = 0; l < 64; ++l) lane2[l] = 0.0f;
+    float segbuf[64];
+    float* seg = S <= 64 ? segbuf : (float*)malloc((size_t)S * sizeof(float));
     for (long s = 0; s < S; ++s) {
         float acc[64];
         const float* us = u + s * GPFQ_SEG;
@@ -151,10 +168,11 @@ float gpfq_oracle_cdot(const float* u, const float* x, long S)
                 a = fmaf(up[3], xp[3], a);
                 acc[l] = a;
             }
-        float seg = tree64(acc);
-        lane2[s & 63] = lane2[s & 63] + seg;
+        seg[s] = tree64(acc);
     }
-    return tree64(lane2);
+    float r = slot_tree(seg, S);
+    if (seg != segbuf) free(seg);
+    return r;
 }
 
 /* ---- the loop ---------------------------------------------------------------------------------- */

@@ -15,14 +15,127 @@ constexpr int kWave = 64;
 
 enum { MODE_MSQ = 0, MODE_SOFT = 1, MODE_HARD = 2, MODE_STOCHASTIC = 3 };
 
-// Balanced pairwise tree over the 64 lanes, result in every lane.  The xor butterfly evaluates, in every
-// lane, exactly the tree ((v0+v1)+(v2+v3))+... of the oracle (fp add is commutative, so both operand
-// orders of a level give the same bits).
+// ---- lane reductions ---------------------------------------------------------------------------
+// DPP controls (gfx9 encoding): quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140.  hipcc folds the move into v_add_f32_dpp.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// v[l] + v[l ^ 16] / v[l ^ 32] through gfx950's v_permlane16_swap / v_permlane32_swap.  The instruction
+// swaps IN PLACE between its two registers: rows {1,3} (resp. lanes 32-63) of the first with rows {0,2}
+// (resp. lanes 0-31) of the second.  Starting from two copies of v, the first ends up holding the even
+// (low) part in every row and the second the odd (high) part, so their sum is the butterfly level.
+// Written as inline asm because hipcc (ROCm 7.2) returns the first output for BOTH results of
+// __builtin_amdgcn_permlane{16,32}_swap (measured on gfx950: tools/scratch/dpp_probe.hip).  The s_nop
+// covers the VALU-write -> permlane-read hazard, which hipcc does not pad inside an asm statement.
+__device__ __forceinline__ float xor16_add(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float xor32_add(float v)
+{
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// Balanced pairwise tree over the 64 lanes, result in every lane: ((v0+v1)+(v2+v3))+... exactly the
+// oracle's tree64 (every level adds the two halves of an aligned block; fp add is commutative, so the
+// mirror / swap forms give the same bits as the xor butterfly).  Needs EXEC = all lanes.
 __device__ __forceinline__ float wave_tree64(float v)
 {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) v = v + __shfl_xor(v, off, kWave);
+    v = v + dpp_mov<0xB1>(v);     // l ^ 1
+    v = v + dpp_mov<0x4E>(v);     // l ^ 2
+    v = v + dpp_mov<0x141>(v);    // other quad of the 8-group (quads are uniform by now)
+    v = v + dpp_mov<0x140>(v);    // other 8-group of the row
+    v = xor16_add(v);
+    v = xor32_add(v);
     return v;
+}
+
+// The same tree over the first nl lanes only (nl a power of two, wave-uniform): the upper levels, which
+// would add the +0.0f of idle lanes, are skipped (adding +0.0f is exact).  Result valid in lanes < nl.
+__device__ __forceinline__ float wave_tree_n(float v, int nl)
+{
+    if (nl > 1) v = v + dpp_mov<0xB1>(v);
+    if (nl > 2) v = v + dpp_mov<0x4E>(v);
+    if (nl > 4) v = v + dpp_mov<0x141>(v);
+    if (nl > 8) v = v + dpp_mov<0x140>(v);
+    if (nl > 16) v = xor16_add(v);
+    if (nl > 32) v = xor32_add(v);
+    return v;
+}
+
+// ---- canonical second level: segment sums -> slots -> pairwise tree -----------------------------
+// A row of S segments uses P = 2^ceil(log2 S) slots; segment s sits in slot floor(s*P/S).  A lane owns
+// `per` consecutive slots starting at slot_base + lane*per; SlotMap remembers which of them are occupied
+// and the first segment among them (segments appear in slot order), computed once per kernel.
+struct SlotMap {
+    int s0;
+    unsigned mask;
+};
+
+__device__ __forceinline__ SlotMap make_slot_map(int S, int P, int slot_base, int per, int lane, int nl)
+{
+    SlotMap mp;
+    mp.s0 = 0;
+    mp.mask = 0u;
+    if (lane < nl) {
+        const int first = slot_base + lane * per;
+        int lo = (first * S + P - 1) / P;
+        int hi = ((first + per) * S + P - 1) / P;
+        if (hi > S) hi = S;
+        mp.s0 = lo;
+        for (int sg = lo; sg < hi; ++sg) mp.mask |= 1u << ((sg * P) / S - first);
+    }
+    return mp;
+}
+
+template <int PER>
+__device__ __forceinline__ float block_tree(const float* seg, const SlotMap mp, int s_last)
+{
+    float v[PER];
+    int sidx = mp.s0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const bool occ = (mp.mask >> k) & 1u;
+        const int si = sidx < s_last ? sidx : s_last;
+        const float val = seg[si];
+        v[k] = occ ? val : 0.0f;
+        sidx += occ ? 1 : 0;
+    }
+#pragma unroll
+    for (int w = 1; w < PER; w <<= 1)
+#pragma unroll
+        for (int i = 0; i < PER; i += 2 * w) v[i] = v[i] + v[i + w];
+    return v[0];
+}
+
+// tree over the slot block [slot_base, slot_base + per*nl) of one row; seg = the row's segment sums
+// (indexed by segment number relative to seg_base); result wave-uniform.
+__device__ __forceinline__ float combine_slots(const float* seg, const SlotMap mp, int per, int nl, int s_last)
+{
+    float v;
+    switch (per) {
+    case 2: v = block_tree<2>(seg, mp, s_last); break;
+    case 4: v = block_tree<4>(seg, mp, s_last); break;
+    case 8: v = block_tree<8>(seg, mp, s_last); break;
+    case 16: v = block_tree<16>(seg, mp, s_last); break;
+    default: v = block_tree<1>(seg, mp, s_last); break;
+    }
+    v = wave_tree_n(v, nl);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+__device__ __forceinline__ int pow2_ceil(int n)
+{
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
 }
 
 // torch.sign: (0 < x) - (x < 0)

@@ -74,14 +74,6 @@ __device__ __forceinline__ void store_u16(const float (&u)[16], float* __restric
     }
 }
 
-// Canonical second level: segment sums seg[0..S) -> lane j adds seg[j], seg[j+64], ... in order; tree64.
-__device__ __forceinline__ float combine_segments(const float* seg, int S, int lane)
-{
-    float v = 0.0f;
-    for (int i = lane; i < S; i += kWave) v = v + seg[i];
-    return wave_tree64(v);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Resident plan: the residual row lives in registers for the whole column loop.  One wave per canonical
 // segment (blockDim.x = 64*S, S <= 16), RT rows per workgroup sharing the activation registers.
@@ -93,6 +85,8 @@ __global__ void __launch_bounds__(1024) gpfq_resident_kernel(LoopParams p)
     extern __shared__ float smem[];                 // [2][RT][S] segment sums, double buffered by step parity
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int S = p.S;
+    const int P = pow2_ceil(S);                     // S <= 16 here: one slot per lane
+    const SlotMap smap = make_slot_map(S, P, 0, 1, lane, P);
     const int g = blockIdx.y;
     const int64_t row0 = (int64_t)blockIdx.x * RT;  // row inside the group
     const int64_t colbase = ((int64_t)g * p.d) * p.m_pad + (int64_t)wave * kSeg + 4 * lane;
@@ -104,35 +98,42 @@ __global__ void __launch_bounds__(1024) gpfq_resident_kernel(LoopParams p)
     int64_t grow[RT];
     bool valid[RT];
     float u[RT][16];
+    const float* __restrict__ wrow[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         valid[r] = (row0 + r) < p.Ng;
         grow[r] = (int64_t)g * p.Ng + (valid[r] ? row0 + r : p.Ng - 1);
+        wrow[r] = p.W + grow[r] * p.ldw;
         if (p.u_has_init) load_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
         else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
         }
     }
-    float qprev[RT];
+    float qprev[RT], wcur[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) qprev[r] = 0.0f;
+    for (int r = 0; r < RT; ++r) { qprev[r] = 0.0f; wcur[r] = wrow[r][0]; }
+    float n2cur = nrm[0];
 
     float xa[16], xb[16], aa[16];
-    if (p.d > 0) { load16(xa, XTp); load16(aa, ATp); }
+    load16(xa, XTp);
+    load16(aa, ATp);
 
     auto body = [&](int64_t t, float (&xc)[16], float (&xo)[16]) {
         // xc = x_t, xo = x_{t-1} (dead after the sweep, then receives x_{t+1})
         float acc[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const float w = p.W[grow[r] * p.ldw + t];
-            acc[r] = (t > 0) ? sweep16<true>(u[r], xo, aa, xc, qprev[r], w)
-                             : sweep16<false>(u[r], xo, aa, xc, 0.0f, w);
-        }
-        if (t + 1 < p.d) {                           // prefetch behind the reduction
+        for (int r = 0; r < RT; ++r)
+            acc[r] = (t > 0) ? sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r])
+                             : sweep16<false>(u[r], xo, aa, xc, 0.0f, wcur[r]);
+        const bool more = t + 1 < p.d;
+        float wn[RT], n2n = 0.0f;
+        if (more) {                                  // prefetch behind the reduction
             load16(xo, XTp + (t + 1) * p.m_pad);
             load16(aa, ATp + (t + 1) * p.m_pad);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
+            n2n = nrm[t + 1];
         }
         float* seg = smem + (size_t)(t & 1) * RT * S;
 #pragma unroll
@@ -141,15 +142,19 @@ __global__ void __launch_bounds__(1024) gpfq_resident_kernel(LoopParams p)
             if (lane == 0) seg[r * S + wave] = sg;
         }
         __syncthreads();
-        const float n2 = nrm[t];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            float tot = combine_segments(seg + r * S, S, lane);
-            float s = (n2 > 0.0f) ? tot / n2 : 0.0f;
+            float tot = combine_slots(seg + r * S, smap, 1, P, S - 1);
+            float s = (n2cur > 0.0f) ? tot / n2cur : 0.0f;
             int id;
             float q = quantize(p.qc, s, p.row_id0 + (uint64_t)grow[r], (uint64_t)t, id);
             qprev[r] = q;
             if (threadIdx.x == 0 && valid[r]) store_q(p, grow[r], t, q, id);
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+            n2cur = n2n;
         }
     };
 
@@ -158,15 +163,13 @@ __global__ void __launch_bounds__(1024) gpfq_resident_kernel(LoopParams p)
     if (t < p.d) body(t, xa, xb);
 
     // pending subtraction of the last step, then write the residual (step_algorithm.py:148)
-    if (p.d > 0) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
+    for (int r = 0; r < RT; ++r) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float xl = (p.d & 1) ? xa[e] : xb[e];
-                float pq = qprev[r] * xl;
-                u[r][e] = u[r][e] - pq;
-            }
+        for (int e = 0; e < 16; ++e) {
+            float xl = (p.d & 1) ? xa[e] : xb[e];
+            float pq = qprev[r] * xl;
+            u[r][e] = u[r][e] - pq;
         }
     }
 #pragma unroll
@@ -185,6 +188,9 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int NW = blockDim.x >> 6;
     const int S = p.S;
+    const int P = pow2_ceil(S);
+    const int per = P > 64 ? P / 64 : 1, nl = P > 64 ? 64 : P;
+    const SlotMap smap = make_slot_map(S, P, 0, per, lane, nl);
     const int g = blockIdx.y;
     const int64_t row0 = (int64_t)blockIdx.x * RT;
     const float* __restrict__ ATg = p.AT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p)
         const float n2 = nrm[t];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            float tot = combine_segments(seg + r * S, S, lane);
+            float tot = combine_slots(seg + r * S, smap, per, nl, S - 1);
             float sv = (n2 > 0.0f) ? tot / n2 : 0.0f;
             int id;
             float q = quantize(p.qc, sv, p.row_id0 + (uint64_t)grow[r], (uint64_t)t, id);
@@ -281,27 +287,28 @@ __global__ void __launch_bounds__(256) gpfq_transpose_pad_kernel(const float* __
     }
 }
 
-// nrm2[t] = (sqrt(cdot(x_t, x_t)))^2, canonical order.  One 256-thread workgroup per column.
+// nrm2[t] = (sqrt(cdot(x_t, x_t)))^2, canonical order.  One 256-thread workgroup per column; dynamic LDS S floats.
 __global__ void __launch_bounds__(256) gpfq_colnorm_kernel(const float* __restrict__ XT, int64_t m_pad, int S,
                                                            float* __restrict__ nrm2)
 {
-    __shared__ float lane2[64];
+    extern __shared__ float seg[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ x = XT + (int64_t)blockIdx.x * m_pad + 4 * lane;
-    if (threadIdx.x < 64) lane2[threadIdx.x] = 0.0f;
-    __syncthreads();
-    for (int s = wave; s < S; s += 4) {          // 64 % 4 == 0: second-level lane s%64 is owned by one wave
+    for (int s = wave; s < S; s += 4) {
         float xv[16];
         load16(xv, x + (int64_t)s * kSeg);
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc = __builtin_fmaf(xv[e], xv[e], acc);
         float sg = wave_tree64(acc);
-        if (lane == 0) lane2[s & 63] = lane2[s & 63] + sg;
+        if (lane == 0) seg[s] = sg;
     }
     __syncthreads();
     if (wave == 0) {
-        float tot = wave_tree64(lane2[lane]);
+        const int P = pow2_ceil(S);
+        const int per = P > 64 ? P / 64 : 1, nl = P > 64 ? 64 : P;
+        const SlotMap smap = make_slot_map(S, P, 0, per, lane, nl);
+        float tot = combine_slots(seg, smap, per, nl, S - 1);
         float r = sqrtf(tot);
         if (lane == 0) nrm2[blockIdx.x] = r * r;
     }
@@ -372,6 +379,7 @@ struct Plan {
 int choose_plan(int64_t Ng, int64_t m_pad, int requested, Plan* out)
 {
     Plan pl;
+    if (m_pad / gpfq::kSeg > 1024) return fail(GPFQ_ERR_UNSUPPORTED, "m > 1048576 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
     if (requested == GPFQ_PLAN_RESIDENT && pl.S > kMaxResidentSegments)
         return fail(GPFQ_ERR_UNSUPPORTED, "resident plan needs m_pad <= 16384");
@@ -477,8 +485,9 @@ int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_
     hipLaunchKernelGGL(gpfq::gpfq_transpose_pad_kernel, grid, dim3(256), 0, st, A, lda, X, ldx, m, D, AT, XT, m_pad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "transpose launch");
-    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(256), 0, st, XT, m_pad,
-                       (int)(m_pad / gpfq::kSeg), nrm2);
+    const int S = (int)(m_pad / gpfq::kSeg);
+    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(256), sizeof(float) * (size_t)S, st, XT, m_pad,
+                       S, nrm2);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "colnorm launch");
     return GPFQ_OK;
