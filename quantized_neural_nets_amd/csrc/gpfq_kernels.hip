@@ -540,8 +540,11 @@ int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const f
 {
     if (!W || !A || !X || !Q || !U || !workspace) return fail(GPFQ_ERR_ARG, "null pointer");
     if (groups < 1 || N < 0 || d_g < 0 || m < 0) return fail(GPFQ_ERR_ARG, "bad shape");
+    if (N % groups != 0) return fail(GPFQ_ERR_ARG, "N must be divisible by groups");
     const int64_t D = d_g * (int64_t)groups;
     if (lda < D || ldx < D) return fail(GPFQ_ERR_ARG, "A / X need groups*d_g columns");
+    int rcm = check_mode(mode, K, idx_bytes, idx);
+    if (rcm) return rcm;
     if (workspace_bytes < gpfq_workspace_bytes(N, d_g, m, groups))
         return fail(GPFQ_ERR_WORKSPACE, "workspace smaller than gpfq_workspace_bytes()");
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(GPFQ_ERR_ARG, "workspace must be 256-byte aligned");

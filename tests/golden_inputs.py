@@ -89,3 +89,30 @@ def load_case(name):
 
 def available_cases():
     return sorted(n for n in CASES if os.path.exists(os.path.join(GOLDEN_DIR, n + ".npz")))
+
+
+# ---- G5: the toy network of the driver-level fixture (tools/make_golden.py gen_driver) ---------------------
+DRIVER_CONFIGS = [dict(bits=4, reg=None, lamb=0.1, retain_rate=0.25),
+                  dict(bits=2, reg='L1', lamb=0.02, retain_rate=0.5),
+                  dict(bits=3, reg=None, lamb=0.1, retain_rate=1)]
+
+
+def toy_net(rng):
+    """conv, grouped strided conv, nested Sequential with a 1x1 conv, two Linear layers; weights from rng."""
+    import torch
+    import torch.nn as nn
+    net = nn.Sequential(
+        nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(),
+        nn.Conv2d(8, 8, 3, stride=2, padding=1, groups=2), nn.ReLU(),
+        nn.Sequential(nn.Conv2d(8, 6, 1), nn.ReLU()),
+        nn.Flatten(), nn.Linear(6 * 6 * 6, 10), nn.ReLU(), nn.Linear(10, 4))
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.from_numpy((rng.standard_normal(tuple(p.shape)) * 0.3).astype(np.float32)))
+    return net.eval()
+
+
+def toy_batches(rng, B, n):
+    import torch
+    return [(torch.from_numpy(rng.standard_normal((B, 3, 12, 12)).astype(np.float32)), torch.zeros(B))
+            for _ in range(n)]

@@ -1,0 +1,62 @@
+"""Driver-level parity on the MI355X: QuantizeNeuralNet(...).quantize_network() on the toy network of the G5
+fixture must reproduce the reference's quantized weights (the fixture was produced by running the reference's
+own quantize_neural_net.py on the CPU with the same seeds, batches and np.random stream)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_quantize_network_matches_reference(ci, capsys):
+    from quantized_neural_nets_amd import QuantizeNeuralNet
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g5_driver.npz"))
+    meta = json.loads(str(fx["meta"]))["configs"][ci]
+    cfg = meta["cfg"]
+    assert cfg == gi.DRIVER_CONFIGS[ci]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(meta["net_seed"])
+    net = gi.toy_net(rng).to(dev)
+    batches = gi.toy_batches(rng, meta["batch"], meta["nlayers"])
+    np.random.seed(meta["np_seed"])
+    torch.manual_seed(meta["np_seed"])
+    quant = QuantizeNeuralNet(net, "toy", meta["batch"], batches, mlp_bits=cfg["bits"], cnn_bits=cfg["bits"],
+                              ignore_layers=[], mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16,
+                              mlp_percentile=1, cnn_percentile=1, reg=cfg["reg"], lamb=cfg["lamb"],
+                              retain_rate=cfg["retain_rate"], stochastic_quantization=False, device=dev)
+    qnet = quant.quantize_network()
+    assert qnet is quant.quantized_network and len(quant.quantized_network_layers) == meta["nlayers"]
+    for li, layer in enumerate(quant.quantized_network_layers):
+        got = layer.weight.detach().cpu().numpy()
+        want = fx["c%d_layer%d_weight" % (ci, li)]
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), "layer %d of config %d differs from the reference" % (li, ci)
+    # analog network untouched, biases untouched
+    rng2 = np.random.default_rng(meta["net_seed"])
+    ref_net = gi.toy_net(rng2)
+    for a, b in zip(quant.analog_network.parameters(), ref_net.parameters()):
+        assert torch.equal(a.cpu(), b)
+    out = capsys.readouterr().out
+    assert "Quantizing layer with index: 4" in out and "The relative quantization error of layer 0" in out
+
+
+def test_ignore_layers_and_unsupported_layer_type():
+    from quantized_neural_nets_amd import QuantizeNeuralNet
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    net = gi.toy_net(rng).to(dev)
+    batches = gi.toy_batches(rng, 4, 5)
+    np.random.seed(0)
+    quant = QuantizeNeuralNet(net, "toy", 4, batches, 4, 4, [0, 3], 1.16, 1.16, 1, 1, None, 0.1, 0.25, False, dev)
+    quant.quantize_network()
+    assert torch.equal(quant.quantized_network_layers[0].weight, quant.analog_network_layers[0].weight)
+    assert torch.equal(quant.quantized_network_layers[3].weight, quant.analog_network_layers[3].weight)
+    assert not torch.equal(quant.quantized_network_layers[1].weight, quant.analog_network_layers[1].weight)
+    w = quant.quantized_network_layers[4].weight
+    assert torch.unique(w).numel() <= 17

@@ -1,0 +1,132 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/gpfq.h declares, the
+argument validation that needs no device, plan selection, the neuron-shard partition and the index->value
+rebuild used after the all_gather."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    so = os.path.join(ROOT, "quantized_neural_nets_amd", "libgpfq_hip.so")
+    if not os.path.exists(so):
+        ge.build()
+    from quantized_neural_nets_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "gpfq.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gpfq_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 10
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "libgpfq_hip.so does not export " + name
+    assert declared == set(lib.EXPORTS), (declared ^ set(lib.EXPORTS))
+    assert lib.lib.gpfq_abi_version() == 1
+
+
+def test_padding_and_workspace(lib):
+    assert lib.lib.gpfq_padded_m(1) == 1024 and lib.lib.gpfq_padded_m(1024) == 1024
+    assert lib.lib.gpfq_padded_m(1025) == 2048 and lib.lib.gpfq_padded_m(93184) == 93184
+    ws = lib.lib.gpfq_workspace_bytes(64, 576, 93184, 1)
+    assert ws >= 2 * 576 * 93184 * 4 + 576 * 4
+
+
+def test_host_side_argument_errors_need_no_gpu(lib):
+    L = lib.lib
+    one = ctypes.c_void_p(256)     # never dereferenced: validation fails first
+    assert L.gpfq_quantizer_f32(7, 0.1, one, 4, 8, 0.0, None, one, None, None) == -1
+    assert L.gpfq_quantizer_f32(0, 0.1, None, 4, 8, 0.0, None, one, None, None) == -1
+    assert L.gpfq_row_absmax_f32(one, 3, 4, 8, one, None) == -1                      # ldw < d
+    assert L.gpfq_prepare_columns_f32(one, 8, one, 8, 100, 8, one, one, one, 512, None) == -1   # m_pad wrong
+    assert b"m_pad" in L.gpfq_last_error()
+    rc = L.gpfq_quantize_layer_f32(one, one, 32, one, 32, 6, 8, 100, 4, 0.1, 8, 0, 0.0, 0, 0, one, None, 1, one, one, 1 << 30, 0, None)
+    assert rc == -1 and b"divisible" in L.gpfq_last_error()                           # N % groups
+    rc = L.gpfq_quantize_layer_f32(one, one, 8, one, 8, 8, 8, 100, 1, 0.1, 8, 0, 0.0, 0, 0, one, None, 1, one, one, 16, 0, None)
+    assert rc == -2                                                                   # workspace too small
+    rc = L.gpfq_quantize_groups_prepared_f32(one, one, one, one, one, one, 8, 8, 100, 1024, 1, 0.1, 200, 0, 0.0, 0, 0,
+                                             one, 1, 0, None)
+    assert rc == -1 and b"int8" in L.gpfq_last_error()                                # K too big for int8
+
+
+def test_plan_selection(lib):
+    assert lib.describe_plan(512, 4608, 3072).startswith("resident")
+    assert lib.describe_plan(256, 2304, 7168).startswith("resident")
+    assert "S=7" in lib.describe_plan(256, 2304, 7168)
+    assert lib.describe_plan(64, 576, 93184, 1, lib.PLAN_STREAM).startswith("stream")
+    assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
+    with pytest.raises(lib.GpfqError):
+        lib.describe_plan(8, 8, 2_000_000)
+
+
+def test_partition_covers_every_neuron_once():
+    from quantized_neural_nets_amd import dist as qd
+    for N, groups, world in [(64, 1, 8), (1000, 1, 8), (7, 1, 8), (32, 32, 8), (96, 96, 5), (24, 2, 8), (24, 3, 4),
+                             (512, 1, 1), (6, 6, 8)]:
+        kind, chunk = qd.partition(N, groups, world)
+        seen = np.zeros(N, int)
+        Ng = N // groups
+        for r in range(world):
+            a, b = qd.local_range(kind, chunk, N, groups, r)
+            assert 0 <= a <= b
+            if kind == "rows":
+                seen[a:b] += 1
+            elif kind == "groups":
+                seen[a * Ng:b * Ng] += 1
+            else:
+                for g in range(groups):
+                    seen[g * Ng + a:g * Ng + b] += 1
+        assert (seen == 1).all(), (N, groups, world, kind)
+        assert kind == ("rows" if groups == 1 else "groups" if groups >= world else "rows_in_groups")
+
+
+def test_rebuild_q_matches_the_quantizers(oracle_mod):
+    """Q rebuilt from gathered indices == the value the quantizer produced (up to the sign of zero)."""
+    from quantized_neural_nets_amd import dist as qd
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(4000) * 0.4).astype(np.float32)
+    for mode in (0, 1, 2):
+        q, idx = oracle_mod.quantizer_vec(mode, 0.0731, x, 8, 0.05)
+        r = qd.rebuild_q(torch.from_numpy(idx.astype(np.int8)), float(np.float32(0.0731)), 8, mode, float(np.float32(0.05)))
+        assert np.array_equal(r.numpy(), q)
+    un = rng.random(4000).astype(np.float32)
+    q, idx = oracle_mod.quantizer_vec(3, 0.0731, x, 8, uniform=un)
+    r = qd.rebuild_q(torch.from_numpy(idx.astype(np.int8)), float(np.float32(0.0731)), 8, 3, 0.0)
+    assert np.array_equal(r.numpy(), q)
+
+
+def test_extract_layers_order_and_whitelist():
+    import torch.nn as nn
+    from quantized_neural_nets_amd.utils import extract_layers, register_block_type
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = nn.Conv2d(2, 2, 1)
+
+    net = nn.Sequential(nn.Conv2d(3, 2, 3), nn.ReLU(), nn.Sequential(nn.Linear(4, 4), nn.Conv2d(2, 2, 1)), Block(),
+                        nn.Linear(4, 2))
+    layers = []
+    extract_layers(net, layers)
+    assert [type(l).__name__ for l in layers] == ["Conv2d", "Linear", "Conv2d", "Linear"]   # Block is not whitelisted
+    register_block_type(Block)
+    layers = []
+    extract_layers(net, layers)
+    assert len(layers) == 5 and layers[3] is net[3].c
+
+
+def test_bench_workload_matches_survey_totals():
+    import bench_workload as bw
+    L = bw.resnet50_3x3_layers(1024)
+    assert len(L) == 16 and sum(n * d for _, n, d, _ in L) == 11317248
+    assert abs(sum(bw.algorithmic_bytes(n, d, m) for _, n, d, m in L) / 1e12 - 0.837) < 1e-3
+    assert {m for *_, m in L} == {93184, 26624, 7168, 3072}

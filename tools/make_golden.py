@@ -213,19 +213,6 @@ def import_reference_driver():
     return quantize_neural_net
 
 
-def toy_net(rng):
-    import torch.nn as nn
-    net = nn.Sequential(
-        nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(),
-        nn.Conv2d(8, 8, 3, stride=2, padding=1, groups=2), nn.ReLU(),
-        nn.Sequential(nn.Conv2d(8, 6, 1), nn.ReLU()),
-        nn.Flatten(), nn.Linear(6 * 6 * 6, 10), nn.ReLU(), nn.Linear(10, 4))
-    with torch.no_grad():
-        for p in net.parameters():
-            p.copy_(torch.from_numpy((rng.standard_normal(tuple(p.shape)) * 0.3).astype(np.float32)))
-    return net.eval()
-
-
 def gen_driver():
     qnn = import_reference_driver()
     out = {}
@@ -234,11 +221,10 @@ def gen_driver():
                               dict(bits=2, reg='L1', lamb=0.02, retain_rate=0.5),
                               dict(bits=3, reg=None, lamb=0.1, retain_rate=1)]):
         rng = np.random.default_rng(777 + ci)
-        net = toy_net(rng)
+        net = gi.toy_net(rng)
         B = 6
         nlayers = 5
-        batches = [(torch.from_numpy(rng.standard_normal((B, 3, 12, 12)).astype(np.float32)), torch.zeros(B))
-                   for _ in range(nlayers)]
+        batches = gi.toy_batches(rng, B, nlayers)
         np.random.seed(11 + ci)
         torch.manual_seed(11 + ci)
         quant = qnn.QuantizeNeuralNet(net, "toy", B, batches, mlp_bits=cfg["bits"], cnn_bits=cfg["bits"],
