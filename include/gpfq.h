@@ -38,7 +38,8 @@ enum {
 enum {
     GPFQ_PLAN_AUTO = 0,
     GPFQ_PLAN_STREAM = 1,     /* residual U streamed through HBM/L2 every step (any size)        */
-    GPFQ_PLAN_RESIDENT = 2    /* residual U resident in registers for the whole column loop      */
+    GPFQ_PLAN_RESIDENT = 2,   /* residual U resident in registers for the whole column loop      */
+    GPFQ_PLAN_COOP = 3        /* resident, each row split by columns over C co-operating workgroups */
 };
 
 /* error codes */
@@ -47,7 +48,8 @@ enum {
     GPFQ_ERR_ARG = -1,        /* bad shape / pointer / enum                                       */
     GPFQ_ERR_WORKSPACE = -2,  /* workspace too small                                              */
     GPFQ_ERR_HIP = -3,        /* a HIP runtime call failed (message has hipGetErrorString)        */
-    GPFQ_ERR_UNSUPPORTED = -4 /* plan cannot run this shape (e.g. forced RESIDENT with huge m)    */
+    GPFQ_ERR_UNSUPPORTED = -4,/* plan cannot run this shape (e.g. forced RESIDENT with huge m)    */
+    GPFQ_ERR_TIMEOUT = -5     /* a cooperative kernel gave up waiting for a peer (gpfq_read_status) */
 };
 
 int gpfq_abi_version(void);
@@ -57,10 +59,24 @@ const char* gpfq_last_error(void);
 int64_t gpfq_padded_m(int64_t m);
 
 /*
- * Bytes of device workspace gpfq_quantize_layer_f32 needs for a layer:
- * transposed+padded activation columns AT, XT [groups*d_g][m_pad], column norms [groups*d_g].
+ * Bytes of device workspace gpfq_quantize_layer_f32 needs for a layer: the scratch area below, then the
+ * transposed+padded activation columns AT, XT [groups*d_g][m_pad] and the column norms [groups*d_g].
  */
 size_t gpfq_workspace_bytes(int64_t N, int64_t d_g, int64_t m, int groups);
+
+/*
+ * Scratch area of the cooperative plan (exchange granules + status words).  256-byte aligned, ZEROED ONCE
+ * by the caller after allocation; the library re-zeroes the granules before every launch and leaves the
+ * status words alone until gpfq_read_status reads them.  Without scratch the cooperative plan is not used.
+ */
+size_t gpfq_scratch_bytes(void);
+
+/*
+ * Synchronises `stream` and copies the 4 status words to the host: [0] != 0 means a cooperative kernel
+ * timed out waiting for a peer workgroup ([1..3] = column, row tile, member) and its outputs are invalid.
+ * Returns GPFQ_ERR_TIMEOUT in that case (and clears the words), else 0.
+ */
+int gpfq_read_status(void* scratch, int* status_host4, void* stream);
 
 /*
  * Column preparation: AT[t][k] = A[k][t], XT[t][k] = X[k][t] for k < m, zero for m <= k < m_pad, and
@@ -85,13 +101,14 @@ int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_
  *   index encoding: msq / soft / stochastic -> k in [-K, K], Q = sign(k)*step*|k|;
  *                   hard -> 0 or +-(k+1), k in [0, K], Q = +-(lamb + step*k)
  *   seed, row_id0: key of the counter-based generator of GPFQ_MODE_STOCHASTIC (row_id0 = global index of row 0)
- *   plan: GPFQ_PLAN_*
+ *   plan: GPFQ_PLAN_*       scratch: gpfq_scratch_bytes() bytes or NULL (then the cooperative plan is not used)
  */
 int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, float* U, int64_t ldu,
                           int u_has_init, const float* AT, const float* XT, const float* nrm2,
                           int64_t N, int64_t d, int64_t m, int64_t m_pad,
                           float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
-                          void* idx, int64_t ldi, int idx_bytes, int plan, void* stream);
+                          void* idx, int64_t ldi, int idx_bytes, int plan, void* scratch, size_t scratch_bytes,
+                          void* stream);
 
 /*
  * One whole layer (all groups in one launch) -- the native part of
@@ -119,7 +136,8 @@ int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const f
 int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const float* AT, const float* XT,
                                       const float* nrm2, int64_t N, int64_t d_g, int64_t m, int64_t m_pad,
                                       int groups, float step, int K, int mode, float lamb, uint64_t seed,
-                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* stream);
+                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* scratch,
+                                      size_t scratch_bytes, void* stream);
 
 /*
  * Elementwise quantizer on a device vector (the four quantizers as standalone ops, for known-answer

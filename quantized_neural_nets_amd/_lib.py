@@ -14,12 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpfq_hip.so")
 
 MODE_MSQ, MODE_SOFT, MODE_HARD, MODE_STOCHASTIC = 0, 1, 2, 3
-PLAN_AUTO, PLAN_STREAM, PLAN_RESIDENT = 0, 1, 2
+PLAN_AUTO, PLAN_STREAM, PLAN_RESIDENT, PLAN_COOP = 0, 1, 2, 3
 
 EXPORTS = [
     "gpfq_abi_version", "gpfq_last_error", "gpfq_padded_m", "gpfq_workspace_bytes",
     "gpfq_prepare_columns_f32", "gpfq_quantization_f32", "gpfq_quantize_layer_f32", "gpfq_quantizer_f32",
-    "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32",
+    "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32", "gpfq_scratch_bytes",
+    "gpfq_read_status",
 ]
 
 
@@ -55,13 +56,16 @@ def _load():
     lib.gpfq_prepare_columns_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, vp, vp, i64, vp]
     lib.gpfq_quantization_f32.restype = i32
     lib.gpfq_quantization_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, i64, i64, i64,
-                                          f32, i32, i32, f32, u64, u64, vp, i64, i32, i32, vp]
+                                          f32, i32, i32, f32, u64, u64, vp, i64, i32, i32, vp, sz, vp]
     lib.gpfq_quantize_layer_f32.restype = i32
     lib.gpfq_quantize_layer_f32.argtypes = [vp, vp, i64, vp, i64, i64, i64, i64, i32, f32, i32, i32, f32, u64, u64,
                                             vp, vp, i32, vp, vp, sz, i32, vp]
     lib.gpfq_quantize_groups_prepared_f32.restype = i32
     lib.gpfq_quantize_groups_prepared_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, i32, i32,
-                                                      f32, u64, u64, vp, i32, i32, vp]
+                                                      f32, u64, u64, vp, i32, i32, vp, sz, vp]
+    lib.gpfq_scratch_bytes.restype = sz
+    lib.gpfq_read_status.restype = i32
+    lib.gpfq_read_status.argtypes = [vp, c.POINTER(c.c_int), vp]
     lib.gpfq_quantizer_f32.restype = i32
     lib.gpfq_quantizer_f32.argtypes = [i32, f32, vp, i64, i32, f32, vp, vp, vp, vp]
     lib.gpfq_row_absmax_f32.restype = i32
@@ -90,6 +94,29 @@ def require_gpu_tensor(t, name):
 
 def current_stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_scratch = {}
+
+
+def scratch(device):
+    """Per-device scratch area of the cooperative plan (allocated and zeroed once)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    buf = _scratch.get(key)
+    if buf is None:
+        buf = torch.zeros((lib.gpfq_scratch_bytes(),), dtype=torch.uint8, device=torch.device("cuda", key))
+        _scratch[key] = buf
+    return buf
+
+
+def check_status(device):
+    """Synchronise and raise if a cooperative kernel reported a timeout since the last check."""
+    buf = scratch(device)
+    st = (ctypes.c_int * 4)()
+    rc = lib.gpfq_read_status(ctypes.c_void_p(buf.data_ptr()), st, current_stream_ptr(buf.device))
+    if rc != 0:
+        raise GpfqError("gpfq error %d: %s (column %d, row tile %d, member %d)" % (
+            rc, lib.gpfq_last_error().decode(), st[1], st[2], st[3]))
 
 
 def describe_plan(N, d_g, m, groups=1, plan=PLAN_AUTO):

@@ -82,7 +82,7 @@ struct SlotMap {
 __device__ __forceinline__ SlotMap make_slot_map(int S, int P, int slot_base, int per, int lane, int nl)
 {
     SlotMap mp;
-    mp.s0 = 0;
+    mp.s0 = (slot_base * S + P - 1) / P;      // idle lanes point at the block's first segment (a valid index)
     mp.mask = 0u;
     if (lane < nl) {
         const int first = slot_base + lane * per;
@@ -127,6 +127,15 @@ __device__ __forceinline__ float combine_slots(const float* seg, const SlotMap m
     case 16: v = block_tree<16>(seg, mp, s_last); break;
     default: v = block_tree<1>(seg, mp, s_last); break;
     }
+    v = wave_tree_n(v, nl);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// combine_slots for blocks of at most 64 slots (one slot per lane): no switch, no per-slot loop
+__device__ __forceinline__ float combine_slots1(const float* seg, const SlotMap mp, int nl)
+{
+    const float val = seg[mp.s0];
+    float v = (mp.mask & 1u) ? val : 0.0f;
     v = wave_tree_n(v, nl);
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }

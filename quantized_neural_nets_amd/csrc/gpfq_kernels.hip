@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 
@@ -75,37 +76,95 @@ __device__ __forceinline__ void store_u16(const float (&u)[16], float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Resident plan: the residual row lives in registers for the whole column loop.  One wave per canonical
-// segment (blockDim.x = 64*S, S <= 16), RT rows per workgroup sharing the activation registers.
-// HBM/L2 traffic per step: only x_{t+1}, a_{t+1} (prefetched behind the reduction of step t).
+// Slab plans (resident / cooperative): the residual lives in registers for the whole column loop.
+//
+// A workgroup owns an RT x (n_own segments) slab of U: RT rows sharing the activation registers, one wave
+// per canonical segment.  Per step: every wave sweeps its segment (fused update + fma chain, sweep16) and
+// reduces the 64 lane chains (wave_tree64); wave 0 then finishes the canonical slot tree, divides by the
+// column norm, quantizes (the RT rows in RT different lanes) and hands q back through LDS.
+//
+//   resident (COOP = false): one workgroup holds whole rows (S <= 16 segments).  HBM/L2 traffic per step is
+//     only x_{t+1}, a_{t+1}, prefetched behind the reduction of step t.
+//   cooperative (COOP = true): a row is split by columns over C workgroups ("members"), needed when rows are
+//     too long for one workgroup's registers or too few to fill the chip.  Each member reduces its own
+//     aligned block of the slot tree, publishes RT partial sums as 8-byte {value, epoch} granules (one
+//     write-through store each: the data is the flag), gathers the C*RT <= 64 granules of its row tile with
+//     one load per lane per poll, finishes the tree over the C members and quantizes.  Every member computes
+//     the same bits, so nothing else is exchanged.  Placement-independent: correctness needs only that all
+//     workgroups are resident (the host sizes the grid from the occupancy query); spins are bounded and a
+//     timeout raises the status word instead of hanging.
 // ------------------------------------------------------------------------------------------------
-template <int RT, bool VEC>
-__global__ void __launch_bounds__(1024) gpfq_resident_kernel(LoopParams p)
-{
-    extern __shared__ float smem[];                 // [2][RT][S] segment sums, double buffered by step parity
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int S = p.S;
-    const int P = pow2_ceil(S);                     // S <= 16 here: one slot per lane
-    const SlotMap smap = make_slot_map(S, P, 0, 1, lane, P);
-    const int g = blockIdx.y;
-    const int64_t row0 = (int64_t)blockIdx.x * RT;  // row inside the group
-    const int64_t colbase = ((int64_t)g * p.d) * p.m_pad + (int64_t)wave * kSeg + 4 * lane;
-    const float* __restrict__ ATp = p.AT + colbase;
-    const float* __restrict__ XTp = p.XT + colbase;
-    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
-    const int64_t kbase = (int64_t)wave * kSeg + 4 * lane;
+struct SlabParams {
+    const float* W; float* Q; float* U; void* idx;
+    const float* AT; const float* XT; const float* nrm2;
+    unsigned long long* xbuf; int* status;
+    int64_t ldw, ldq, ldu, ldi, m, m_pad;
+    int Ng, d, S, C, tiles, idx_bytes, u_has_init, vec;
+    float step, Kf, lamb;
+    unsigned spin_limit;
+    uint64_t seed, row_id0;
+};
 
-    int64_t grow[RT];
-    bool valid[RT];
+template <int MODE>
+__device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uint64_t row, uint64_t col, int& id)
+{
+    if (MODE == MODE_SOFT) return quant_soft(p.step, s, p.Kf, p.lamb, id);
+    if (MODE == MODE_HARD) return quant_hard(p.step, s, p.Kf, p.lamb, id);
+    if (MODE == MODE_STOCHASTIC) return quant_stochastic(p.step, s, p.Kf, philox_uniform(p.seed, row, col), id);
+    return quant_msq(p.step, s, p.Kf, id);
+}
+
+template <int RT, int MODE, bool COOP>
+__global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const SlabParams p)
+{
+    extern __shared__ float smem[];                 // seg[2][RT][NW], then qs[2][RT + 1]
+    const int NW = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int S = p.S, C = COOP ? p.C : 1;
+    const int P = pow2_ceil(S);
+    int tile, c, g;
+    if (COOP) {
+        g = 0;
+        // keep the members of one row tile on one XCD when the tile count allows it (blocks b and b+8 share an
+        // XCD under round-robin dispatch; speed only, never correctness)
+        if ((p.tiles & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            tile = (j / C) * 8 + xcd;
+            c = j % C;
+        } else {
+            tile = blockIdx.x / C;
+            c = blockIdx.x % C;
+        }
+    } else {
+        tile = blockIdx.x; c = 0; g = blockIdx.y;
+    }
+    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
+    const int n_own = seg_hi - seg_lo;              // <= NW
+    const bool active = wave < n_own;
+    const int myseg = seg_lo + (active ? wave : 0);
+    const int nl = P / C;                           // slots of this workgroup's block: <= 64 (host guarantees it)
+    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane, nl);
+
+    float* segs = smem;                             // [2][RT][NW]
+    float* qs = smem + 2 * RT * NW;                 // [2][RT + 1]   (last = abort flag)
+
+    const int row0 = tile * RT;                     // row inside the group
+    const int64_t grow0 = (int64_t)g * p.Ng + row0; // global row of this tile's first row
+    const int64_t kbase = (int64_t)myseg * kSeg + 4 * lane;
+    const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+
     float u[RT][16];
     const float* __restrict__ wrow[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-        valid[r] = (row0 + r) < p.Ng;
-        grow[r] = (int64_t)g * p.Ng + (valid[r] ? row0 + r : p.Ng - 1);
-        wrow[r] = p.W + grow[r] * p.ldw;
-        if (p.u_has_init) load_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
-        else {
+        const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
+        wrow[r] = p.W + gr * p.ldw;
+        if (p.u_has_init && active) {
+            if (p.vec) load_u16<true>(u[r], p.U + gr * p.ldu, kbase, p.m);
+            else load_u16<false>(u[r], p.U + gr * p.ldu, kbase, p.m);
+        } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
         }
@@ -116,65 +175,128 @@ __global__ void __launch_bounds__(1024) gpfq_resident_kernel(LoopParams p)
     float n2cur = nrm[0];
 
     float xa[16], xb[16], aa[16];
-    load16(xa, XTp);
-    load16(aa, ATp);
-
-    auto body = [&](int64_t t, float (&xc)[16], float (&xo)[16]) {
-        // xc = x_t, xo = x_{t-1} (dead after the sweep, then receives x_{t+1})
-        float acc[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
-            acc[r] = (t > 0) ? sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r])
-                             : sweep16<false>(u[r], xo, aa, xc, 0.0f, wcur[r]);
+    for (int e = 0; e < 16; ++e) { xa[e] = 0.0f; xb[e] = 0.0f; aa[e] = 0.0f; }
+    if (active) { load16(xa, xcol); load16(aa, acol); }
+
+    bool dead = false;
+    int t = 0;
+    auto body = [&](float (&xc)[16], float (&xo)[16]) {
+        // xc = x_t, xo = x_{t-1} (all zero at t = 0, where q_{-1} = 0; dead after the sweep, then receives x_{t+1})
+        const int par = t & 1;
         const bool more = t + 1 < p.d;
+        float* seg = segs + par * RT * NW;
         float wn[RT], n2n = 0.0f;
-        if (more) {                                  // prefetch behind the reduction
-            load16(xo, XTp + (t + 1) * p.m_pad);
-            load16(aa, ATp + (t + 1) * p.m_pad);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = 0.0f;
+        if (active) {
+            float acc[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r]);
+            if (more) {
+                xcol += p.m_pad;
+                acol += p.m_pad;
+                load16(xo, xcol);
+                load16(aa, acol);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float sg = wave_tree64(acc[r]);
+                if (lane == 0) seg[r * NW + wave] = sg;
+            }
+        }
+        if (more) {
 #pragma unroll
             for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
             n2n = nrm[t + 1];
         }
-        float* seg = smem + (size_t)(t & 1) * RT * S;
+        __syncthreads();
+        if (wave == 0) {
+            // this workgroup's block of the slot tree: one value per row, row r parked in lane r
+            float mine = 0.0f;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            float sg = wave_tree64(acc[r]);
-            if (lane == 0) seg[r * S + wave] = sg;
+            for (int r = 0; r < RT; ++r) {
+                const float pr = combine_slots1(seg + r * NW - seg_lo, smap, nl);
+                if (lane == r) mine = pr;
+            }
+            float v = mine;
+            bool timed_out = false;
+            if (COOP) {
+                const unsigned epoch = (unsigned)t + 1u;
+                unsigned long long* xb_ = p.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
+                if (lane < RT)
+                    __hip_atomic_store(xb_ + (size_t)c * RT + lane,
+                                       ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(mine),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // gather: lane = r*C + member
+                const bool want = lane < RT * C;
+                const unsigned long long* src = xb_ + (want ? (size_t)(lane % C) * RT + (lane / C) : 0);
+                unsigned long long gv = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = !want || ((unsigned)(gv >> 32) == epoch);
+                    if (__all(ok)) break;
+                    if (++spins > p.spin_limit) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                v = want ? __uint_as_float((unsigned)gv) : 0.0f;
+                v = wave_tree_n(v, C);               // upper levels of the slot tree, per aligned block of C lanes
+            }
+            const int gr_ = lane / C;                // row of this lane (lanes r*C .. r*C+C-1 hold row r's total)
+            const bool lead = (lane % C == 0) && gr_ < RT;
+            const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+            const bool rvalid = lead && (row0 + gr_ < p.Ng);
+            const int64_t growl = grow0 + (rvalid ? gr_ : 0);
+            int id;
+            const float q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
+            if (lead) qs[par * (RT + 1) + gr_] = q;
+            if (rvalid && c == 0) {
+                p.Q[growl * p.ldq + t] = q;
+                if (p.idx) {
+                    if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[growl * p.ldi + t] = (int8_t)id;
+                    else reinterpret_cast<int16_t*>(p.idx)[growl * p.ldi + t] = (int16_t)id;
+                }
+            }
+            if (COOP && lane == 0) {
+                qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
+                if (timed_out) {
+                    atomicExch(p.status, 1);
+                    p.status[1] = t; p.status[2] = tile; p.status[3] = c;
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            float tot = combine_slots(seg + r * S, smap, 1, P, S - 1);
-            float s = (n2cur > 0.0f) ? tot / n2cur : 0.0f;
-            int id;
-            float q = quantize(p.qc, s, p.row_id0 + (uint64_t)grow[r], (uint64_t)t, id);
-            qprev[r] = q;
-            if (threadIdx.x == 0 && valid[r]) store_q(p, grow[r], t, q, id);
-        }
-        if (more) {
+        for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
+        if (COOP) dead = qs[par * (RT + 1) + RT] != 0.0f;
 #pragma unroll
-            for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
-            n2cur = n2n;
-        }
+        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+        n2cur = n2n;
+        ++t;
     };
 
-    int64_t t = 0;
-    for (; t + 1 < p.d; t += 2) { body(t, xa, xb); body(t + 1, xb, xa); }
-    if (t < p.d) body(t, xa, xb);
+    while (t < p.d && !dead) {
+        body(xa, xb);
+        if (t < p.d && !dead) body(xb, xa);
+    }
+    if (dead || !active) return;
 
     // pending subtraction of the last step, then write the residual (step_algorithm.py:148)
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            float xl = (p.d & 1) ? xa[e] : xb[e];
-            float pq = qprev[r] * xl;
+            const float xl = (p.d & 1) ? xa[e] : xb[e];
+            const float pq = qprev[r] * xl;
             u[r][e] = u[r][e] - pq;
         }
+        if (row0 + r < p.Ng) {
+            float* Urow = p.U + (grow0 + r) * p.ldu;
+            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
+            else store_u16<false>(u[r], Urow, kbase, p.m);
+        }
     }
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-        if (valid[r]) store_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,66 +490,210 @@ int hip_fail(hipError_t e, const char* what)
 }
 
 constexpr int kMaxResidentSegments = 16;
+constexpr int kMaxCoopWaves = 12;
+constexpr size_t kScratchBytes = 128 * 1024;        // [0, 96 KiB) exchange granules, [96 KiB, ...) status words
+constexpr size_t kScratchStatusOffset = 96 * 1024;
 
 struct Plan {
-    int kind;      // GPFQ_PLAN_STREAM / GPFQ_PLAN_RESIDENT
+    int kind;      // GPFQ_PLAN_STREAM / GPFQ_PLAN_RESIDENT / GPFQ_PLAN_COOP
     int RT;        // rows per workgroup
     int waves;     // waves per workgroup
     int S;         // segments per row
+    int C;         // coop: members per row tile
+    int tiles;     // coop: row tiles
 };
 
-int choose_plan(int64_t Ng, int64_t m_pad, int requested, Plan* out)
+int device_cu_count()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+int floor_pow2(int64_t n)
+{
+    int p = 1;
+    while ((int64_t)p * 2 <= n) p *= 2;
+    return p;
+}
+
+// Cooperative configuration: maximise the number of co-resident workgroups (<= capacity), then prefer more
+// rows per workgroup (fewer activation bytes per residual element).  Depends on (Ng, S, CU count) only.
+bool choose_coop(int64_t Ng, int S, int capacity, Plan* pl)
+{
+    const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
+    int best_wgs = 0;
+    bool found = false;
+    for (int RT = 4; RT >= 1; RT >>= 1) {
+        if (force_rt && RT != force_rt) continue;
+        const int64_t tiles = (Ng + RT - 1) / RT;
+        if (tiles > capacity) continue;
+        int C = 64 / RT;
+        const int by_cap = floor_pow2(capacity / tiles), by_s = floor_pow2(S);
+        if (C > by_cap) C = by_cap;
+        if (C > by_s) C = by_s;
+        if (force_c) C = force_c;
+        if (C < 2 || C * RT > 64 || C > S || tiles * C > capacity || (C & (C - 1))) continue;
+        const int NW = (S + C - 1) / C;
+        if (NW > kMaxCoopWaves) continue;
+        const int wgs = (int)tiles * C;
+        if (!found || wgs > best_wgs) {
+            found = true;
+            best_wgs = wgs;
+            pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
+        }
+    }
+    return found;
+}
+
+int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, Plan* out)
 {
     Plan pl;
+    pl.C = 1; pl.tiles = 0;
     if (m_pad / gpfq::kSeg > 1024) return fail(GPFQ_ERR_UNSUPPORTED, "m > 1048576 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
+    if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_COOP) return fail(GPFQ_ERR_ARG, "unknown plan id");
     if (requested == GPFQ_PLAN_RESIDENT && pl.S > kMaxResidentSegments)
         return fail(GPFQ_ERR_UNSUPPORTED, "resident plan needs m_pad <= 16384");
     if (requested == GPFQ_PLAN_RESIDENT || (requested == GPFQ_PLAN_AUTO && pl.S <= kMaxResidentSegments)) {
         pl.kind = GPFQ_PLAN_RESIDENT;
         pl.RT = 1;
         pl.waves = pl.S;
-    } else if (requested == GPFQ_PLAN_STREAM || requested == GPFQ_PLAN_AUTO) {
-        pl.kind = GPFQ_PLAN_STREAM;
-        pl.RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
-        pl.waves = pl.S < 8 ? pl.S : 8;
-    } else {
-        return fail(GPFQ_ERR_ARG, "unknown plan id");
+        *out = pl;
+        return GPFQ_OK;
     }
+    if (requested == GPFQ_PLAN_COOP || (requested == GPFQ_PLAN_AUTO && !env_int("GPFQ_COOP_DISABLE", 0))) {
+        const int capacity = device_cu_count() * (env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1);
+        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, capacity, &pl)) {
+            *out = pl;
+            return GPFQ_OK;
+        }
+        if (requested == GPFQ_PLAN_COOP)
+            return fail(GPFQ_ERR_UNSUPPORTED, "cooperative plan needs groups == 1, a scratch buffer and a shape that fits");
+    }
+    pl.kind = GPFQ_PLAN_STREAM;
+    pl.RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
+    pl.waves = pl.S < 8 ? pl.S : 8;
     *out = pl;
     return GPFQ_OK;
 }
 
 template <int RT>
-hipError_t launch_loop(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, hipStream_t st)
+hipError_t launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, hipStream_t st)
 {
     dim3 grid((unsigned)((p.Ng + RT - 1) / RT), (unsigned)groups, 1);
     dim3 block((unsigned)(64 * pl.waves), 1, 1);
     size_t shm = sizeof(float) * 2 * RT * (size_t)p.S;
-    if (pl.kind == GPFQ_PLAN_RESIDENT) {
-        if (vec) hipLaunchKernelGGL((gpfq::gpfq_resident_kernel<RT, true>), grid, block, shm, st, p);
-        else hipLaunchKernelGGL((gpfq::gpfq_resident_kernel<RT, false>), grid, block, shm, st, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, true>), grid, block, shm, st, p);
-        else hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, false>), grid, block, shm, st, p);
-    }
+    if (vec) hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, true>), grid, block, shm, st, p);
+    else hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, false>), grid, block, shm, st, p);
     return hipGetLastError();
 }
 
-int run_loop(gpfq::LoopParams p, int groups, int plan, hipStream_t st)
+gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, bool vec, void* scratch)
+{
+    gpfq::SlabParams sp;
+    sp.W = p.W; sp.Q = p.Q; sp.U = p.U; sp.idx = p.idx; sp.AT = p.AT; sp.XT = p.XT; sp.nrm2 = p.nrm2;
+    sp.xbuf = reinterpret_cast<unsigned long long*>(scratch);
+    sp.status = scratch ? reinterpret_cast<int*>(static_cast<char*>(scratch) + kScratchStatusOffset) : nullptr;
+    sp.ldw = p.ldw; sp.ldq = p.ldq; sp.ldu = p.ldu; sp.ldi = p.ldi; sp.m = p.m; sp.m_pad = p.m_pad;
+    sp.Ng = (int)p.Ng; sp.d = (int)p.d; sp.S = pl.S; sp.C = pl.C; sp.tiles = pl.tiles; sp.idx_bytes = p.idx_bytes;
+    sp.u_has_init = p.u_has_init; sp.vec = vec ? 1 : 0;
+    sp.step = p.qc.step; sp.Kf = p.qc.Kf; sp.lamb = p.qc.lamb;
+    sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
+    sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
+    return sp;
+}
+
+template <int RT, int MODE, bool COOP>
+int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* scratch, hipStream_t st)
+{
+    const int threads = 64 * pl.waves;
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)pl.waves + 2 * (RT + 1));
+    hipError_t e;
+    dim3 grid;
+    if (COOP) {
+        const int nblocks = pl.tiles * pl.C;
+        // every workgroup must be resident at once: check the grid against the occupancy query, keeping one
+        // block per CU of margin when more than one block per CU is needed (the query can over-report by one)
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_kernel<RT, MODE, COOP>, threads, shm);
+        if (e != hipSuccess) return hip_fail(e, "occupancy query");
+        const int cus = device_cu_count();
+        const int need = (nblocks + cus - 1) / cus;
+        if (nb < 1 || need > nb || (need > 1 && nb < need + 1))
+            return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
+        size_t xbytes = (size_t)pl.tiles * 2 * pl.C * RT * sizeof(unsigned long long);
+        xbytes = (xbytes + 15) & ~(size_t)15;
+        if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
+        e = hipMemsetAsync(scratch, 0, xbytes, st);
+        if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
+        grid = dim3((unsigned)nblocks, 1, 1);
+    } else {
+        grid = dim3((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
+    }
+    hipLaunchKernelGGL((gpfq::gpfq_slab_kernel<RT, MODE, COOP>), grid, dim3((unsigned)threads), shm, st, sp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "GPFQ slab kernel launch");
+    return GPFQ_OK;
+}
+
+template <int RT, bool COOP>
+int launch_slab_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, void* scratch, hipStream_t st)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return launch_slab_t<RT, gpfq::MODE_SOFT, COOP>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_HARD: return launch_slab_t<RT, gpfq::MODE_HARD, COOP>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_STOCHASTIC: return launch_slab_t<RT, gpfq::MODE_STOCHASTIC, COOP>(pl, sp, groups, scratch, st);
+    default: return launch_slab_t<RT, gpfq::MODE_MSQ, COOP>(pl, sp, groups, scratch, st);
+    }
+}
+
+int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, void* scratch, hipStream_t st)
+{
+    const gpfq::SlabParams sp = make_slab_params(pl, p, vec, scratch);
+    if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_slab_m<1, false>(pl, sp, p.qc.mode, groups, scratch, st);
+    switch (pl.RT) {
+    case 4: return launch_slab_m<4, true>(pl, sp, p.qc.mode, groups, scratch, st);
+    case 2: return launch_slab_m<2, true>(pl, sp, p.qc.mode, groups, scratch, st);
+    default: return launch_slab_m<1, true>(pl, sp, p.qc.mode, groups, scratch, st);
+    }
+}
+
+int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scratch_bytes, hipStream_t st)
 {
     if (p.Ng <= 0 || p.d <= 0 || groups <= 0) return GPFQ_OK;   // nothing to do
+    if (p.Ng > 0x7fffffff || p.d > 0x7fffffff) return fail(GPFQ_ERR_UNSUPPORTED, "N or d beyond 2^31");
+    const bool have_scratch = scratch && scratch_bytes >= kScratchBytes && !(reinterpret_cast<uintptr_t>(scratch) & 255);
     Plan pl;
-    int rc = choose_plan(p.Ng, p.m_pad, plan, &pl);
+    int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, &pl);
     if (rc) return rc;
     if (groups > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "groups > 65535");
     p.S = pl.S;
     const bool vec = ((p.ldu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.U) & 15) == 0);
+    if (pl.kind == GPFQ_PLAN_COOP) {
+        rc = launch_slab(pl, p, groups, vec, scratch, st);
+        if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
+        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, false, &pl);   // does not fit: stream instead
+        if (rc) return rc;
+    }
+    if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_slab(pl, p, groups, vec, scratch, st);
     hipError_t e;
     switch (pl.RT) {
-    case 4: e = launch_loop<4>(pl, p, groups, vec, st); break;
-    case 2: e = launch_loop<2>(pl, p, groups, vec, st); break;
-    default: e = launch_loop<1>(pl, p, groups, vec, st); break;
+    case 4: e = launch_stream<4>(pl, p, groups, vec, st); break;
+    case 2: e = launch_stream<2>(pl, p, groups, vec, st); break;
+    default: e = launch_stream<1>(pl, p, groups, vec, st); break;
     }
     if (e != hipSuccess) return hip_fail(e, "GPFQ loop launch");
     return GPFQ_OK;
@@ -459,15 +725,39 @@ int64_t gpfq_padded_m(int64_t m)
     return ((m + gpfq::kSeg - 1) / gpfq::kSeg) * gpfq::kSeg;
 }
 
+size_t gpfq_scratch_bytes(void) { return kScratchBytes; }
+
+static size_t ws_cols_bytes(int64_t d_g, int64_t m, int groups)
+{
+    const size_t D = (size_t)d_g * (size_t)groups;
+    return D * (size_t)gpfq_padded_m(m) * sizeof(float);
+}
+static size_t ws_nrm_bytes(int64_t d_g, int groups)
+{
+    return (((size_t)d_g * (size_t)groups * sizeof(float) + 255) / 256) * 256;
+}
+
 size_t gpfq_workspace_bytes(int64_t N, int64_t d_g, int64_t m, int groups)
 {
     (void)N;
     if (d_g < 0 || m < 0 || groups < 1) return 0;
-    const size_t D = (size_t)d_g * (size_t)groups;
-    const size_t mp = (size_t)gpfq_padded_m(m);
-    size_t cols = D * mp * sizeof(float);
-    size_t nrm = ((D * sizeof(float) + 255) / 256) * 256;
-    return 2 * cols + nrm + 256;
+    return kScratchBytes + 2 * ws_cols_bytes(d_g, m, groups) + ws_nrm_bytes(d_g, groups) + 256;
+}
+
+int gpfq_read_status(void* scratch, int* status_host4, void* stream)
+{
+    if (!scratch || !status_host4) return fail(GPFQ_ERR_ARG, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    char* sp = static_cast<char*>(scratch) + kScratchStatusOffset;
+    hipError_t e = hipMemcpyAsync(status_host4, sp, 4 * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(e, "status read");
+    if (status_host4[0] != 0) {
+        e = hipMemsetAsync(sp, 0, 4 * sizeof(int), st);
+        if (e != hipSuccess) return hip_fail(e, "status reset");
+        return fail(GPFQ_ERR_TIMEOUT, "cooperative kernel timed out waiting for a peer workgroup");
+    }
+    return GPFQ_OK;
 }
 
 int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
@@ -497,7 +787,8 @@ int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, fl
                           int u_has_init, const float* AT, const float* XT, const float* nrm2,
                           int64_t N, int64_t d, int64_t m, int64_t m_pad,
                           float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
-                          void* idx, int64_t ldi, int idx_bytes, int plan, void* stream)
+                          void* idx, int64_t ldi, int idx_bytes, int plan, void* scratch, size_t scratch_bytes,
+                          void* stream)
 {
     if (!W || !Q || !U || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
     if (N < 0 || d < 0 || m < 0 || ldw < d || ldq < d || ldu < m || (idx && ldi < d))
@@ -510,13 +801,14 @@ int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, fl
     p.AT = AT; p.XT = XT; p.nrm2 = nrm2; p.Ng = N; p.d = d; p.m = m; p.m_pad = m_pad; p.S = 0;
     p.qc.step = step; p.qc.Kf = (float)K; p.qc.lamb = lamb; p.qc.mode = mode; p.qc.seed = seed;
     p.row_id0 = row_id0; p.idx = idx; p.ldi = ldi; p.idx_bytes = idx_bytes;
-    return run_loop(p, 1, plan, (hipStream_t)stream);
+    return run_loop(p, 1, plan, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const float* AT, const float* XT,
                                       const float* nrm2, int64_t N, int64_t d_g, int64_t m, int64_t m_pad,
                                       int groups, float step, int K, int mode, float lamb, uint64_t seed,
-                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* stream)
+                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* scratch,
+                                      size_t scratch_bytes, void* stream)
 {
     if (!W || !Q || !U || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
     if (groups < 1 || N < 0 || d_g < 0 || m < 0) return fail(GPFQ_ERR_ARG, "bad shape");
@@ -529,7 +821,7 @@ int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const 
     p.AT = AT; p.XT = XT; p.nrm2 = nrm2; p.Ng = N / groups; p.d = d_g; p.m = m; p.m_pad = m_pad; p.S = 0;
     p.qc.step = step; p.qc.Kf = (float)K; p.qc.lamb = lamb; p.qc.mode = mode; p.qc.seed = seed;
     p.row_id0 = row_id0; p.idx = idx; p.ldi = d_g; p.idx_bytes = idx_bytes;
-    return run_loop(p, groups, plan, (hipStream_t)stream);
+    return run_loop(p, groups, plan, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const float* X, int64_t ldx,
@@ -549,14 +841,15 @@ int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const f
         return fail(GPFQ_ERR_WORKSPACE, "workspace smaller than gpfq_workspace_bytes()");
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(GPFQ_ERR_ARG, "workspace must be 256-byte aligned");
     const int64_t mp = gpfq_padded_m(m);
-    char* ws = static_cast<char*>(workspace);
-    float* AT = reinterpret_cast<float*>(ws);
-    float* XT = reinterpret_cast<float*>(ws + (size_t)D * mp * sizeof(float));
-    float* nrm2 = reinterpret_cast<float*>(ws + 2 * (size_t)D * mp * sizeof(float));
+    char* ws = static_cast<char*>(workspace);          // [scratch][AT][XT][nrm2]
+    const size_t cb = ws_cols_bytes(d_g, m, groups);
+    float* AT = reinterpret_cast<float*>(ws + kScratchBytes);
+    float* XT = reinterpret_cast<float*>(ws + kScratchBytes + cb);
+    float* nrm2 = reinterpret_cast<float*>(ws + kScratchBytes + 2 * cb);
     int rc = gpfq_prepare_columns_f32(A, lda, X, ldx, m, D, AT, XT, nrm2, mp, stream);
     if (rc) return rc;
     return gpfq_quantize_groups_prepared_f32(W, Q, U, AT, XT, nrm2, N, d_g, m, mp, groups, step, K, mode, lamb, seed,
-                                             row_id0, idx, idx_bytes, plan, stream);
+                                             row_id0, idx, idx_bytes, plan, ws, kScratchBytes, stream);
 }
 
 int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, float lamb,
@@ -588,12 +881,17 @@ int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, 
 {
     if (groups < 1 || N % groups != 0) return fail(GPFQ_ERR_ARG, "bad groups");
     Plan pl;
-    int rc = choose_plan(N / groups, gpfq_padded_m(m), plan, &pl);
+    int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, &pl);
     if (rc) return rc;
-    if (buf && buf_bytes)
-        snprintf(buf, buf_bytes, "%s RT=%d waves=%d S=%d grid=(%lld,%d) d=%lld",
-                 pl.kind == GPFQ_PLAN_RESIDENT ? "resident" : "stream", pl.RT, pl.waves, pl.S,
-                 (long long)((N / groups + pl.RT - 1) / pl.RT), groups, (long long)d_g);
+    if (buf && buf_bytes) {
+        if (pl.kind == GPFQ_PLAN_COOP)
+            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
+                     pl.tiles * pl.C, (long long)d_g);
+        else
+            snprintf(buf, buf_bytes, "%s RT=%d waves=%d S=%d grid=(%lld,%d) d=%lld",
+                     pl.kind == GPFQ_PLAN_RESIDENT ? "resident" : "stream", pl.RT, pl.waves, pl.S,
+                     (long long)((N / groups + pl.RT - 1) / pl.RT), groups, (long long)d_g);
+    }
     return pl.kind;
 }
 

@@ -119,6 +119,7 @@ class StepAlgorithm:
         XT = torch.empty((max(d, 1), mp), device=dev, dtype=torch.float32)
         nrm2 = torch.empty((max(d, 1),), device=dev, dtype=torch.float32)
         st = _lib.current_stream_ptr(dev)
+        scr = _lib.scratch(dev)
         _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A), lda, _ptr(X), ldx, m, d, _ptr(AT), _ptr(XT),
                                                      _ptr(nrm2), mp, st))
         seed = StepAlgorithm.stochastic_seed
@@ -127,7 +128,8 @@ class StepAlgorithm:
         _lib.check(_lib.lib.gpfq_quantization_f32(
             _ptr(Wv), ldw, _ptr(Qv), ldq, _ptr(Uv), ldu, 1, _ptr(AT), _ptr(XT), _ptr(nrm2), N, d, m, mp,
             float(step_size), int(boundary_idx), mode, float(lamb if lamb is not None else 0.0), seed, 0,
-            None, 0, 1, StepAlgorithm.plan, st))
+            None, 0, 1, StepAlgorithm.plan, _ptr(scr), scr.numel(), st))
+        _lib.check_status(dev)
         if Qv.data_ptr() != Q.data_ptr():
             Q.copy_(Qv)
         if Uv.data_ptr() != U.data_ptr():
@@ -191,6 +193,7 @@ class StepAlgorithm:
         idx_dtype, idx_bytes = _idx_dtype(K)
         dev = W.device
         st = _lib.current_stream_ptr(dev)
+        scr = _lib.scratch(dev)
 
         def run_rows(W_loc, groups_loc, A_loc, lda_loc, X_loc, ldx_loc, row_id0):
             """all groups of a (sub)layer in one launch; returns Q, idx, U for those rows"""
@@ -217,7 +220,8 @@ class StepAlgorithm:
                 hook("loop_begin", (Nl, dg, mm, groups_loc))
             _lib.check(_lib.lib.gpfq_quantize_groups_prepared_f32(
                 _ptr(W_loc), _ptr(Q), _ptr(U), _ptr(AT), _ptr(XT), _ptr(nrm2), Nl, dg, mm, mp, groups_loc,
-                step, K, mode, lamb_f, seed, int(row_id0), _ptr(idx), idx_bytes, StepAlgorithm.plan, st))
+                step, K, mode, lamb_f, seed, int(row_id0), _ptr(idx), idx_bytes, StepAlgorithm.plan,
+                _ptr(scr), scr.numel(), st))
             if hook:
                 hook("loop_end", (Nl, dg, mm, groups_loc))
             return Q, idx, U
@@ -231,6 +235,7 @@ class StepAlgorithm:
                                                      idx_dtype, run_rows)
         out = dict(Q=Q, idx=idx, U=U, step=step_t, rows=rows)
         if compute_errors:
+            _lib.check_status(dev)      # synchronises; raises if a cooperative kernel timed out
             out.update(StepAlgorithm._error_metrics(W, A, U, groups, rows, shard))
         return out
 

@@ -37,11 +37,27 @@ def test_full_size_layer_row_subset_and_plans_agree(shape):
     assert torch.equal(part["U"], full["U"][37:101])
     _, _, _, st = _layer(1, shape, 1234 + 40)
     assert torch.equal(st["idx"], full["idx"]) and torch.equal(st["U"], full["U"]) and torch.equal(st["Q"], full["Q"])
+    _, _, _, co = _layer(3, shape, 1234 + 40)       # cooperative: rows split over several workgroups
+    assert torch.equal(co["idx"], full["idx"]) and torch.equal(co["U"], full["U"]) and torch.equal(co["Q"], full["Q"])
     assert int(full["idx"].abs().max()) <= 8
     # residual identity: U == A-projected error, i.e. U = W A^T - Q X^T up to fp32 accumulation
     Wd, Ad, Xd = W.to(DEV).double(), A.to(DEV).double(), X.to(DEV).double()
     ref = Wd @ Ad.T - full["Q"].double() @ Xd.T
     assert (full["U"].double() - ref).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(64, 576, 93184), (128, 1152, 26624)])
+def test_full_size_long_rows_cooperative_equals_streaming(shape):
+    """ResNet-50 layer1.*.conv2 / layer2.{1,2,3}.conv2 at batch 1024: AUTO (cooperative) == streaming, bit for bit,
+    and a row subset equals the slice of the full result."""
+    from quantized_neural_nets_amd import _lib
+    assert _lib.describe_plan(shape[0], shape[1], shape[2]).startswith("coop")
+    W, A, X, full = _layer(0, shape, 1234 + 7, d_limit=300)
+    _lib.check_status(DEV)
+    _, _, _, st = _layer(1, shape, 1234 + 7, d_limit=300)
+    assert torch.equal(st["idx"], full["idx"]) and torch.equal(st["U"], full["U"])
+    _, _, _, part = _layer(0, shape, 1234 + 7, rows=(5, 30), d_limit=300)
+    assert torch.equal(part["idx"], full["idx"][5:30]) and torch.equal(part["U"], full["U"][5:30])
 
 
 def test_full_size_layer_against_oracle(oracle_mod):

@@ -31,8 +31,13 @@ def _t(a):
 
 
 def _run_layer(qnn, case, W, A, X, plan=0):
-    from quantized_neural_nets_amd import StepAlgorithm
+    from quantized_neural_nets_amd import StepAlgorithm, _lib
     K = 2 ** (case["bits"] - 1)
+    if plan == 3:
+        try:
+            _lib.describe_plan(W.shape[0], W.shape[1], A.shape[0], case["groups"], 3)
+        except _lib.GpfqError:
+            pytest.skip("cooperative plan does not apply to this shape")
     StepAlgorithm.plan = plan
     try:
         r = StepAlgorithm._quantize_layer_ex(_t(W), _t(A), _t(X), A.shape[0], case["scalar"] / K, K,
@@ -67,7 +72,7 @@ def test_stochastic_quantizer_is_unbiased(qnn):
 
 
 @pytest.mark.parametrize("name", gi.available_cases())
-@pytest.mark.parametrize("plan", [0, 1])
+@pytest.mark.parametrize("plan", [0, 1, 3])
 def test_layer_against_reference_and_oracle(qnn, oracle_mod, name, plan):
     case, (W, A, X), fx, meta = gi.load_case(name)
     r = _run_layer(qnn, case, W, A, X, plan)
@@ -110,7 +115,7 @@ RANDOM_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", RANDOM_SHAPES)
-@pytest.mark.parametrize("plan", [0, 1])
+@pytest.mark.parametrize("plan", [0, 1, 3])
 def test_random_shapes_bit_exact_vs_oracle(qnn, oracle_mod, shape, plan):
     N, d, m, groups, mode, bits = shape
     reg = {"msq": None, "soft": "L1", "hard": "L0"}[mode]
@@ -124,6 +129,29 @@ def test_random_shapes_bit_exact_vs_oracle(qnn, oracle_mod, shape, plan):
     assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
     assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
     assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+
+
+@pytest.mark.parametrize("rt,c", [(1, 4), (1, 16), (2, 4), (2, 16), (4, 4), (4, 8), (4, 16)])
+@pytest.mark.parametrize("mode", ["msq", "hard"])
+def test_cooperative_configurations(qnn, oracle_mod, monkeypatch, rt, c, mode):
+    """Forced (rows per workgroup, members per row) pairs of the cooperative plan, ragged row tiles included:
+    every configuration reproduces the oracle bit for bit (the slot tree makes the order independent of C)."""
+    N, d, m, bits = 11, 20, 40000, 4            # S = 40 segments; 11 rows -> ragged tiles for RT = 2, 4
+    reg = {"msq": None, "hard": "L0"}[mode]
+    case = dict(name="coop_%s" % mode, N=N, d=d, m=m, bits=bits, scalar=1.16, percentile=1.0, reg=reg, lamb=0.02,
+                groups=1, first_layer=False, zero_every=6, seed=9)
+    W, A, X = gi.make_inputs(case)
+    monkeypatch.setenv("GPFQ_COOP_RT", str(rt))
+    monkeypatch.setenv("GPFQ_COOP_C", str(c))
+    from quantized_neural_nets_amd import _lib
+    desc = _lib.describe_plan(N, d, m, 1, 3)
+    assert desc.startswith("coop RT=%d C=%d" % (rt, c)), desc
+    r = _run_layer(qnn, case, W, A, X, 3)
+    _lib.check_status(DEV)
+    o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, reg, 0.02, 1)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+    assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
 
 
 def test_quantization_in_place_with_initial_residual_and_views(qnn, oracle_mod):

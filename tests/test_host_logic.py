@@ -54,7 +54,7 @@ def test_host_side_argument_errors_need_no_gpu(lib):
     rc = L.gpfq_quantize_layer_f32(one, one, 8, one, 8, 8, 8, 100, 1, 0.1, 8, 0, 0.0, 0, 0, one, None, 1, one, one, 16, 0, None)
     assert rc == -2                                                                   # workspace too small
     rc = L.gpfq_quantize_groups_prepared_f32(one, one, one, one, one, one, 8, 8, 100, 1024, 1, 0.1, 200, 0, 0.0, 0, 0,
-                                             one, 1, 0, None)
+                                             one, 1, 0, None, 0, None)
     assert rc == -1 and b"int8" in L.gpfq_last_error()                                # K too big for int8
 
 
@@ -63,6 +63,12 @@ def test_plan_selection(lib):
     assert lib.describe_plan(256, 2304, 7168).startswith("resident")
     assert "S=7" in lib.describe_plan(256, 2304, 7168)
     assert lib.describe_plan(64, 576, 93184, 1, lib.PLAN_STREAM).startswith("stream")
+    assert lib.describe_plan(64, 576, 93184).startswith("coop RT=4 C=16 waves=6")
+    assert lib.describe_plan(128, 1152, 93184).startswith("coop RT=4 C=8 waves=12")
+    assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=4 C=8 waves=4")
+    assert lib.describe_plan(256, 2304, 26624).startswith("coop RT=4 C=4 waves=7")
+    assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=32 waves=3")       # an 8-GPU shard of 64 rows
+    assert lib.describe_plan(64, 9, 30000, 64).startswith("stream")                     # grouped: never cooperative
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
     with pytest.raises(lib.GpfqError):
         lib.describe_plan(8, 8, 2_000_000)
