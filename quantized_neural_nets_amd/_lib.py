@@ -11,7 +11,7 @@ import subprocess
 import torch  # noqa: F401  (must precede loading the library, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpfq_hip.so")
+LIB_PATH = os.environ.get("GPFQ_LIB_OVERRIDE") or os.path.join(_HERE, "libgpfq_hip.so")   # override: diagnostic builds
 
 MODE_MSQ, MODE_SOFT, MODE_HARD, MODE_STOCHASTIC = 0, 1, 2, 3
 PLAN_AUTO, PLAN_STREAM, PLAN_RESIDENT, PLAN_COOP = 0, 1, 2, 3

@@ -99,7 +99,7 @@ struct SlabParams {
     const float* AT; const float* XT; const float* nrm2;
     unsigned long long* xbuf; int* status;
     int64_t ldw, ldq, ldu, ldi, m, m_pad;
-    int Ng, d, S, C, tiles, idx_bytes, u_has_init, vec;
+    int Ng, d, S, C, tiles, idx_bytes, vec;
     float step, Kf, lamb;
     unsigned spin_limit;
     uint64_t seed, row_id0;
@@ -114,8 +114,10 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
     return quant_msq(p.step, s, p.Kf, id);
 }
 
-template <int RT, int MODE, bool COOP>
-__global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const SlabParams p)
+// MAXW = most waves per workgroup the instantiation may be launched with; it sets the register budget
+// (16 waves -> 128 VGPRs, 12 -> 168, 8 -> 256): more rows per workgroup need the roomier variants.
+template <int RT, int MODE, bool COOP, int MAXW>
+__global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p)
 {
     extern __shared__ float smem[];                 // seg[2][RT][NW], then qs[2][RT + 1]
     const int NW = blockDim.x >> 6;
@@ -139,11 +141,18 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
         tile = blockIdx.x; c = 0; g = blockIdx.y;
     }
     const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
-    const int n_own = seg_hi - seg_lo;              // <= NW
+    const int n_own = seg_hi - seg_lo;              // <= max_own
+    const int max_own = (S + C - 1) / C;            // sweep waves of the fullest member
+    // The reducer (slot tree, exchange, quantizer) is a wave of its own when the launch has one to spare
+    // (NW == max_own + 1): its serial section is then not delayed by its own column loads; otherwise wave 0
+    // doubles as the reducer.
+    const int rwave = NW > max_own ? max_own : 0;
     const bool active = wave < n_own;
     const int myseg = seg_lo + (active ? wave : 0);
-    const int nl = P / C;                           // slots of this workgroup's block: <= 64 (host guarantees it)
-    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane, nl);
+    const int nl = P / C;                           // slots of this workgroup's block; RT*nl <= 64 (host guarantees it)
+    // wave 0 reduces all RT rows at once: lane = r*nl + slot
+    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane % nl, nl);
+    const int rlane = lane / nl;                    // row whose slot this lane holds (>= RT: idle)
 
     float* segs = smem;                             // [2][RT][NW]
     float* qs = smem + 2 * RT * NW;                 // [2][RT + 1]   (last = abort flag)
@@ -161,28 +170,43 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
     for (int r = 0; r < RT; ++r) {
         const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
         wrow[r] = p.W + gr * p.ldw;
-        if (p.u_has_init && active) {
-            if (p.vec) load_u16<true>(u[r], p.U + gr * p.ldu, kbase, p.m);
-            else load_u16<false>(u[r], p.U + gr * p.ldu, kbase, p.m);
-        } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
-        }
+        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;   // a non-zero initial residual is the streaming plan's job
     }
     float qprev[RT], wcur[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) { qprev[r] = 0.0f; wcur[r] = wrow[r][0]; }
     float n2cur = nrm[0];
 
-    float xa[16], xb[16], aa[16];
+    // xc = x_t, xo = x_{t-1} (all zero at t = 0, where q_{-1} = 0), aa = a_t
+    float xc[16], xo[16], aa[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { xa[e] = 0.0f; xb[e] = 0.0f; aa[e] = 0.0f; }
-    if (active) { load16(xa, xcol); load16(aa, acol); }
+    for (int e = 0; e < 16; ++e) { xc[e] = 0.0f; xo[e] = 0.0f; aa[e] = 0.0f; }
+    if (active) { load16(xc, xcol); load16(aa, acol); }
 
+#ifdef GPFQ_STAMPS
+    // diagnostic build only: cycles per phase, summed by wave 0 (and the last wave) of block 0 into status[16..]
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_prev = 0;
+#define GPFQ_STAMP(i)                                                                                   \
+    {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long now_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        stamp_sum[i] += now_ - stamp_prev;                                                              \
+        stamp_prev = now_;                                                                              \
+    }
+#else
+#define GPFQ_STAMP(i)
+#endif
     bool dead = false;
     int t = 0;
-    auto body = [&](float (&xc)[16], float (&xo)[16]) {
-        // xc = x_t, xo = x_{t-1} (all zero at t = 0, where q_{-1} = 0; dead after the sweep, then receives x_{t+1})
+#ifdef GPFQ_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    while (t < p.d && !dead) {
+        GPFQ_STAMP(0)
         const int par = t & 1;
         const bool more = t + 1 < p.d;
         float* seg = segs + par * RT * NW;
@@ -193,17 +217,13 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
             float acc[RT];
 #pragma unroll
             for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r]);
-            if (more) {
-                xcol += p.m_pad;
-                acol += p.m_pad;
-                load16(xo, xcol);
-                load16(aa, acol);
-            }
+            GPFQ_STAMP(1)
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const float sg = wave_tree64(acc[r]);
                 if (lane == 0) seg[r * NW + wave] = sg;
             }
+            GPFQ_STAMP(2)
         }
         if (more) {
 #pragma unroll
@@ -211,22 +231,40 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
             n2n = nrm[t + 1];
         }
         __syncthreads();
-        if (wave == 0) {
-            // this workgroup's block of the slot tree: one value per row, row r parked in lane r
-            float mine = 0.0f;
+        GPFQ_STAMP(3)
+        // Next column's loads, issued OFF the critical path (the sweep waves idle until the reducer is done) and
+        // landing in the registers the sweep just finished with.  The opaque asm keeps LLVM from hoisting them
+        // (they depend on nothing here): hoisted above the sweep they need 32 more VGPRs and a copy that waits
+        // for them before the barrier, and their issue stalls (~60-180 cycles each) sit on the critical path.
+        auto issue_loads = [&]() {
 #pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                const float pr = combine_slots1(seg + r * NW - seg_lo, smap, nl);
-                if (lane == r) mine = pr;
+            for (int e = 0; e < 16; ++e) xo[e] = xc[e];
+            int64_t adv = more ? p.m_pad : 0;        // the last step re-reads its own column: no join copy
+            asm volatile("" : "+s"(adv)::"memory");
+            xcol += adv;
+            acol += adv;
+            load16(xc, xcol);
+            load16(aa, acol);
+        };
+        if (active && wave != rwave) issue_loads();
+        if (wave == rwave) {
+            // this workgroup's block of the slot tree for all RT rows at once: blocks of nl lanes
+            float v;
+            {
+                const int rr = rlane < RT ? rlane : 0;
+                const float val = seg[rr * NW + (smap.s0 - seg_lo)];
+                v = ((smap.mask & 1u) && rlane < RT) ? val : 0.0f;
+                v = wave_tree_n(v, nl);
             }
-            float v = mine;
             bool timed_out = false;
+            int blk = nl;                            // lanes r*blk .. r*blk+blk-1 hold row r's value
+            GPFQ_STAMP(4)
             if (COOP) {
                 const unsigned epoch = (unsigned)t + 1u;
                 unsigned long long* xb_ = p.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
-                if (lane < RT)
-                    __hip_atomic_store(xb_ + (size_t)c * RT + lane,
-                                       ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(mine),
+                if ((lane % nl) == 0 && rlane < RT)
+                    __hip_atomic_store(xb_ + (size_t)c * RT + rlane,
+                                       ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // gather: lane = r*C + member
                 const bool want = lane < RT * C;
@@ -242,9 +280,11 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
                 }
                 v = want ? __uint_as_float((unsigned)gv) : 0.0f;
                 v = wave_tree_n(v, C);               // upper levels of the slot tree, per aligned block of C lanes
+                blk = C;
             }
-            const int gr_ = lane / C;                // row of this lane (lanes r*C .. r*C+C-1 hold row r's total)
-            const bool lead = (lane % C == 0) && gr_ < RT;
+            GPFQ_STAMP(5)
+            const int gr_ = lane / blk;              // row of this lane
+            const bool lead = (lane % blk == 0) && gr_ < RT;
             const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
             const bool rvalid = lead && (row0 + gr_ < p.Ng);
             const int64_t growl = grow0 + (rvalid ? gr_ : 0);
@@ -266,7 +306,10 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
                 }
             }
         }
+        if (active && wave == rwave) issue_loads();
+        GPFQ_STAMP(6)
         __syncthreads();
+        GPFQ_STAMP(7)
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
         if (COOP) dead = qs[par * (RT + 1) + RT] != 0.0f;
@@ -274,12 +317,13 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
         ++t;
-    };
-
-    while (t < p.d && !dead) {
-        body(xa, xb);
-        if (t < p.d && !dead) body(xb, xa);
     }
+#ifdef GPFQ_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == rwave || wave == (rwave == 0 ? NW - 1 : 0)) && p.status) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 16) + (wave == rwave ? 0 : 8);
+        for (int i = 0; i < 8; ++i) dbg[i] = stamp_sum[i];
+    }
+#endif
     if (dead || !active) return;
 
     // pending subtraction of the last step, then write the residual (step_algorithm.py:148)
@@ -287,8 +331,7 @@ __global__ void __launch_bounds__(COOP ? 768 : 1024) gpfq_slab_kernel(const Slab
     for (int r = 0; r < RT; ++r) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const float xl = (p.d & 1) ? xa[e] : xb[e];
-            const float pq = qprev[r] * xl;
+            const float pq = qprev[r] * xo[e];       // xo = x_{d-1} after the last rotation
             u[r][e] = u[r][e] - pq;
         }
         if (row0 + r < p.Ng) {
@@ -490,7 +533,6 @@ int hip_fail(hipError_t e, const char* what)
 }
 
 constexpr int kMaxResidentSegments = 16;
-constexpr int kMaxCoopWaves = 12;
 constexpr size_t kScratchBytes = 128 * 1024;        // [0, 96 KiB) exchange granules, [96 KiB, ...) status words
 constexpr size_t kScratchStatusOffset = 96 * 1024;
 
@@ -529,30 +571,46 @@ int floor_pow2(int64_t n)
     return p;
 }
 
-// Cooperative configuration: maximise the number of co-resident workgroups (<= capacity), then prefer more
-// rows per workgroup (fewer activation bytes per residual element).  Depends on (Ng, S, CU count) only.
-bool choose_coop(int64_t Ng, int S, int capacity, Plan* pl)
+int slab_max_waves(bool coop, int RT);
+
+// Cost model of one column step (microseconds), fitted to MI355X measurements (tools/layer_bench.py): a fixed
+// latency (barriers, reductions, quantizer; plus the granule exchange when cooperative), RT sweeps issued by a
+// wave that owns its SIMD slot, and the per-CU column traffic / issue contention that grows with the waves on a CU.
+double slab_step_cost(int RT, int waves, int C)
+{
+    return 0.5 + 0.285 * RT + 0.134 * waves + (C >= 16 ? 0.9 : 0.0);
+}
+
+// Cooperative configuration: cheapest modelled step among the (RT, C) pairs whose grid is co-resident.
+// Depends on (Ng, S, CU count) only -- never on the data.
+bool choose_coop(int64_t Ng, int S, int cus, Plan* pl)
 {
     const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
-    int best_wgs = 0;
+    const int wgs_per_cu = env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1;
+    const int capacity = cus * wgs_per_cu;
+    double best = 1e30;
     bool found = false;
     for (int RT = 4; RT >= 1; RT >>= 1) {
         if (force_rt && RT != force_rt) continue;
         const int64_t tiles = (Ng + RT - 1) / RT;
         if (tiles > capacity) continue;
-        int C = 64 / RT;
-        const int by_cap = floor_pow2(capacity / tiles), by_s = floor_pow2(S);
-        if (C > by_cap) C = by_cap;
-        if (C > by_s) C = by_s;
-        if (force_c) C = force_c;
-        if (C < 2 || C * RT > 64 || C > S || tiles * C > capacity || (C & (C - 1))) continue;
-        const int NW = (S + C - 1) / C;
-        if (NW > kMaxCoopWaves) continue;
-        const int wgs = (int)tiles * C;
-        if (!found || wgs > best_wgs) {
-            found = true;
-            best_wgs = wgs;
-            pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
+        for (int C = 64 / RT; C >= 2; C >>= 1) {
+            if (force_c && C != force_c) continue;
+            if (C > S || tiles * C > capacity) continue;
+            const int NW = (S + C - 1) / C;
+            if (NW > slab_max_waves(true, RT)) continue;
+            const int wgs = (int)tiles * C;
+            const int per_cu = (wgs + cus - 1) / cus;
+            if ((per_cu * NW + 3) / 4 > 4) continue;
+            // rounds of work if the grid does not cover the chip are not modelled: fewer workgroups than CUs
+            // simply leave CUs idle, which costs nothing per step
+            double cost = slab_step_cost(RT, per_cu * NW, C);
+            if (RT == 4 && NW > 8) cost += 1.2;      // the 12-wave RT=4 variant spills registers
+            if (!found || cost < best - 1e-9) {
+                found = true;
+                best = cost;
+                pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
+            }
         }
     }
     return found;
@@ -567,16 +625,24 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_COOP) return fail(GPFQ_ERR_ARG, "unknown plan id");
     if (requested == GPFQ_PLAN_RESIDENT && pl.S > kMaxResidentSegments)
         return fail(GPFQ_ERR_UNSUPPORTED, "resident plan needs m_pad <= 16384");
+    const int cus = device_cu_count();
     if (requested == GPFQ_PLAN_RESIDENT || (requested == GPFQ_PLAN_AUTO && pl.S <= kMaxResidentSegments)) {
         pl.kind = GPFQ_PLAN_RESIDENT;
-        pl.RT = 1;
         pl.waves = pl.S;
+        // rows per workgroup: share the activation registers between rows once there are more rows than the
+        // chip has room for one-row workgroups (the roomier variants exist for <= 8 waves)
+        pl.RT = 1;
+        const int force_rt = env_int("GPFQ_RESIDENT_RT", 0);
+        if (pl.S <= 8) {
+            // measured (tools/layer_bench.py): one row per workgroup is never slower than two or four on the
+            // ResNet-50 shapes; the larger variants exist for experiments (GPFQ_RESIDENT_RT)
+            if (force_rt == 1 || force_rt == 2 || force_rt == 4) pl.RT = force_rt;
+        }
         *out = pl;
         return GPFQ_OK;
     }
     if (requested == GPFQ_PLAN_COOP || (requested == GPFQ_PLAN_AUTO && !env_int("GPFQ_COOP_DISABLE", 0))) {
-        const int capacity = device_cu_count() * (env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1);
-        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, capacity, &pl)) {
+        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, &pl)) {
             *out = pl;
             return GPFQ_OK;
         }
@@ -609,30 +675,34 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.status = scratch ? reinterpret_cast<int*>(static_cast<char*>(scratch) + kScratchStatusOffset) : nullptr;
     sp.ldw = p.ldw; sp.ldq = p.ldq; sp.ldu = p.ldu; sp.ldi = p.ldi; sp.m = p.m; sp.m_pad = p.m_pad;
     sp.Ng = (int)p.Ng; sp.d = (int)p.d; sp.S = pl.S; sp.C = pl.C; sp.tiles = pl.tiles; sp.idx_bytes = p.idx_bytes;
-    sp.u_has_init = p.u_has_init; sp.vec = vec ? 1 : 0;
+    sp.vec = vec ? 1 : 0;
     sp.step = p.qc.step; sp.Kf = p.qc.Kf; sp.lamb = p.qc.lamb;
     sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     return sp;
 }
 
-template <int RT, int MODE, bool COOP>
+template <int RT, int MODE, bool COOP, int MAXW>
 int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* scratch, hipStream_t st)
 {
-    const int threads = 64 * pl.waves;
-    const size_t shm = sizeof(float) * (2 * RT * (size_t)pl.waves + 2 * (RT + 1));
+    if (pl.waves > MAXW) return fail(GPFQ_ERR_UNSUPPORTED, "internal: waves exceed the kernel variant's bound");
+    // one more wave for the reducer role when the variant's register budget allows it
+    const int nwaves = pl.waves + ((pl.waves + 1 <= MAXW && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
+    const int threads = 64 * nwaves;
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1));
     hipError_t e;
     dim3 grid;
     if (COOP) {
         const int nblocks = pl.tiles * pl.C;
-        // every workgroup must be resident at once: check the grid against the occupancy query, keeping one
-        // block per CU of margin when more than one block per CU is needed (the query can over-report by one)
+        // every workgroup must be resident at once: check the grid against the occupancy query (the query is
+        // known to over-report by one only near the SGPR limit of >= 6 waves per SIMD; these kernels run at
+        // <= 4, so the answer is taken as is -- and every spin is bounded anyway)
         int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_kernel<RT, MODE, COOP>, threads, shm);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>, threads, shm);
         if (e != hipSuccess) return hip_fail(e, "occupancy query");
         const int cus = device_cu_count();
         const int need = (nblocks + cus - 1) / cus;
-        if (nb < 1 || need > nb || (need > 1 && nb < need + 1))
+        if (nb < 1 || need > nb || (need * nwaves + 3) / 4 > 4)
             return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
         size_t xbytes = (size_t)pl.tiles * 2 * pl.C * RT * sizeof(unsigned long long);
         xbytes = (xbytes + 15) & ~(size_t)15;
@@ -643,32 +713,47 @@ int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* 
     } else {
         grid = dim3((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
     }
-    hipLaunchKernelGGL((gpfq::gpfq_slab_kernel<RT, MODE, COOP>), grid, dim3((unsigned)threads), shm, st, sp);
+    hipLaunchKernelGGL((gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>), grid, dim3((unsigned)threads), shm, st, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ slab kernel launch");
     return GPFQ_OK;
 }
 
-template <int RT, bool COOP>
+template <int RT, bool COOP, int MAXW>
 int launch_slab_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, void* scratch, hipStream_t st)
 {
     switch (mode) {
-    case gpfq::MODE_SOFT: return launch_slab_t<RT, gpfq::MODE_SOFT, COOP>(pl, sp, groups, scratch, st);
-    case gpfq::MODE_HARD: return launch_slab_t<RT, gpfq::MODE_HARD, COOP>(pl, sp, groups, scratch, st);
-    case gpfq::MODE_STOCHASTIC: return launch_slab_t<RT, gpfq::MODE_STOCHASTIC, COOP>(pl, sp, groups, scratch, st);
-    default: return launch_slab_t<RT, gpfq::MODE_MSQ, COOP>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_SOFT: return launch_slab_t<RT, gpfq::MODE_SOFT, COOP, MAXW>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_HARD: return launch_slab_t<RT, gpfq::MODE_HARD, COOP, MAXW>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_STOCHASTIC: return launch_slab_t<RT, gpfq::MODE_STOCHASTIC, COOP, MAXW>(pl, sp, groups, scratch, st);
+    default: return launch_slab_t<RT, gpfq::MODE_MSQ, COOP, MAXW>(pl, sp, groups, scratch, st);
     }
 }
 
+// The instantiated (rows per workgroup, wave bound) pairs -- keep slab_variant_ok() in step with this switch.
 int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, void* scratch, hipStream_t st)
 {
     const gpfq::SlabParams sp = make_slab_params(pl, p, vec, scratch);
-    if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_slab_m<1, false>(pl, sp, p.qc.mode, groups, scratch, st);
-    switch (pl.RT) {
-    case 4: return launch_slab_m<4, true>(pl, sp, p.qc.mode, groups, scratch, st);
-    case 2: return launch_slab_m<2, true>(pl, sp, p.qc.mode, groups, scratch, st);
-    default: return launch_slab_m<1, true>(pl, sp, p.qc.mode, groups, scratch, st);
+    const int m = p.qc.mode;
+    if (pl.kind == GPFQ_PLAN_RESIDENT) {
+        if (pl.RT == 1) return launch_slab_m<1, false, 16>(pl, sp, m, groups, scratch, st);
+        if (pl.RT == 2) return launch_slab_m<2, false, 8>(pl, sp, m, groups, scratch, st);
+        return launch_slab_m<4, false, 8>(pl, sp, m, groups, scratch, st);
     }
+    if (pl.RT == 1) return launch_slab_m<1, true, 12>(pl, sp, m, groups, scratch, st);
+    if (pl.RT == 2) {
+        if (pl.waves <= 8) return launch_slab_m<2, true, 8>(pl, sp, m, groups, scratch, st);
+        return launch_slab_m<2, true, 12>(pl, sp, m, groups, scratch, st);
+    }
+    if (pl.waves <= 8) return launch_slab_m<4, true, 8>(pl, sp, m, groups, scratch, st);
+    return launch_slab_m<4, true, 12>(pl, sp, m, groups, scratch, st);   // 168-VGPR budget: spills a little
+}
+
+// most waves per workgroup an instantiation exists for
+int slab_max_waves(bool coop, int RT)
+{
+    if (!coop) return RT == 1 ? 16 : 8;
+    return 12;
 }
 
 int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scratch_bytes, hipStream_t st)
@@ -677,6 +762,11 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     if (p.Ng > 0x7fffffff || p.d > 0x7fffffff) return fail(GPFQ_ERR_UNSUPPORTED, "N or d beyond 2^31");
     const bool have_scratch = scratch && scratch_bytes >= kScratchBytes && !(reinterpret_cast<uintptr_t>(scratch) & 255);
     Plan pl;
+    // the register-resident plans start from U = 0; a caller-provided initial residual (the in-place
+    // _quantization surface) streams through memory
+    if (p.u_has_init && plan == GPFQ_PLAN_AUTO) plan = GPFQ_PLAN_STREAM;
+    if (p.u_has_init && plan != GPFQ_PLAN_STREAM)
+        return fail(GPFQ_ERR_UNSUPPORTED, "an initial residual needs the streaming plan");
     int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, &pl);
     if (rc) return rc;
     if (groups > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "groups > 65535");

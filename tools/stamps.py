@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the slab kernel (needs `make -C quantized_neural_nets_amd/csrc stamps`).
+   GPFQ_LIB_OVERRIDE=.../libgpfq_hip_stamps.so python tools/stamps.py N,d,m [ENV=..]"""
+import ctypes, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench_workload as bw
+from quantized_neural_nets_amd import StepAlgorithm, _lib
+names = ["top/loop", "sweep", "prefetch+tree64+ldsw", "barrier1", "combine", "exchange", "quantize+store", "barrier2"]
+dev = torch.device("cuda:0")
+for a in sys.argv[1:]:
+    if "=" in a:
+        k, v = a.split("="); os.environ[k] = v; continue
+    N, d, m = (int(v) for v in a.split(","))
+    dl = min(d, 512)
+    W, A, X = bw.synthetic_layer(N, d, m, 99, d_limit=dl)
+    step = bw.layer_step(W)
+    for it in range(2):
+        StepAlgorithm._quantize_layer_ex(W.to(dev), A.to(dev), X.to(dev), m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev,
+                                         compute_errors=False, step_override=step)
+    torch.cuda.synchronize()
+    scr = _lib.scratch(dev)
+    dbg = scr[96 * 1024 + 64: 96 * 1024 + 64 + 128].view(torch.int64).cpu().tolist()
+    print(a, _lib.describe_plan(N, dl, m))
+    for w, off in (("wave0", 0), ("lastwave", 8)):
+        tot = sum(dbg[off:off + 8])
+        print("  %-8s total %.0f cyc/step:" % (w, tot / dl), "  ".join("%s %.0f" % (names[i], dbg[off + i] / dl) for i in range(8)))
