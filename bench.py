@@ -76,6 +76,33 @@ def cpu_baseline(layers, budget_s=16.0):
             "host_cores": ncores, "c_oracle_value": round(tot_w_c / tot_t_c / 1e6, 5)}
 
 
+def kernel_name(desc):
+    """The template instantiation a plan description launches (quantized_neural_nets_amd/csrc launch_slab):
+    the names rocprofv3 reports."""
+    w = desc.split()
+    kv = dict(x.split("=") for x in w[1:] if "=" in x)
+    rt, waves = int(kv["RT"]), int(kv["waves"])
+    if w[0] == "resident":
+        return "gpfq_slab_kernel<%d, 0, false, %d>" % (rt, 16 if rt == 1 else 8)
+    if w[0] == "coop":
+        return "gpfq_slab_kernel<%d, 0, true, %d>" % (rt, 12 if (rt == 1 or waves > 8) else 8)
+    return "gpfq_stream_kernel<%d, true>" % rt
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (tools/pmc_traffic.py:
+    separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 FETCH_SIZE correction applied)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for name, v in data.get("kernels", {}).items():
+        if kernel in name:
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,15 +208,16 @@ def main():
             kind_, chunk = qdist.partition(N, 1, world)
             a, b = qdist.local_range(kind_, chunk, N, 1, rank)
             Nl = b - a
-        kind = _lib.describe_plan(max(Nl, 1), d, m).split()[0]
+        desc = _lib.describe_plan(max(Nl, 1), d, m)
+        kind = kernel_name(desc)
         f = fam.setdefault(kind, {"ms": 0.0, "bytes": 0.0, "launches": 0})
         f["ms"] += rec["loop_ms"]
         f["bytes"] += bw.algorithmic_bytes(Nl, d, m) * rec["n"]
         f["launches"] += rec["n"]
         if rank == 0:
             lm, pm = rec["loop_ms"] / rec["n"], rec["prep_ms"] / rec["n"]
-            log("%-16s N=%4d d=%5d m=%6d %-8s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg, %5.1f%% of 8 TB/s)  prep %7.3f ms"
-                % (name, N, d, m, kind, lm, lm * 1e3 / d, bw.algorithmic_bytes(Nl, d, m) / lm / 1e6,
+            log("%-16s N=%4d d=%5d m=%6d %-24s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg, %5.1f%% of 8 TB/s)  prep %7.3f ms"
+                % (name, N, d, m, " ".join(desc.split()[:3]), lm, lm * 1e3 / d, bw.algorithmic_bytes(Nl, d, m) / lm / 1e6,
                    bw.algorithmic_bytes(Nl, d, m) / lm / 1e6 / HBM_PEAK_GBPS * 100, pm))
 
     if rank == 0:
@@ -198,9 +226,10 @@ def main():
         if dom:
             f = fam[dom]
             achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "gpfq_%s_kernel" % dom, "achieved": round(achieved, 1),
+            traffic, tsrc = pmc_traffic(dom)
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                        "traffic": None, "launches": f["launches"],
+                        "traffic": traffic, "traffic_source": tsrc, "launches": f["launches"],
                         "avg_launch_ms": round(f["ms"] / f["launches"], 4),
                         "alg_bytes_per_launch": round(f["bytes"] / f["launches"]),
                         "families": {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],
