@@ -355,195 +355,6 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Slab kernel with LDS-DMA column staging.  Same slabs, same arithmetic, same reducer as gpfq_slab_kernel;
-// what changes is how x_t / a_t reach the sweep waves.  Register-destination loads block the issuing wave
-// for the whole issue (measured ~150 cycles per 1-KB instruction with every CU loading: 1.2-2 k cycles per
-// step), so here every sweep wave owns an 8-KB LDS staging area that `global_load_lds_dwordx4` fills
-// asynchronously (no VGPR destination, ~25-60 cycles to issue): while step t is swept, reduced and quantized,
-// the DMA of column t+2 is in flight; after the first barrier the wave copies column t+1 from its staging
-// area into registers (ds_read_b128, off the critical path) and re-arms the DMA.
-//   - no compiler-visible vector loads inside the loop (a use would make hipcc drain vmcnt): W and the column
-//     norms come in 64-step chunks through LDS (refilled by the reducer), waits are explicit;
-//   - raw s_barrier + lgkmcnt(0) instead of __syncthreads(), which would drain the DMA.
-// ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef const __attribute__((address_space(1))) void* glb_vptr;
-
-__device__ __forceinline__ void dma_column(const float* gcol, float* stage)
-{
-    // 4 x 1 KiB: lane l's 16 bytes of chunk c go to stage + c*1024 B + l*16 B (the instruction's own layout)
-    const glb_vptr g = (glb_vptr)gcol;
-    const lds_vptr l = (lds_vptr)(uintptr_t)stage;
-    __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
-}
-
-__device__ __forceinline__ void read_staged(float (&dst)[16], const float* stage, int lane)
-{
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(stage + 256 * c + 4 * lane);
-        dst[4 * c + 0] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
-    }
-}
-
-__device__ __forceinline__ void wg_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <int RT, int MODE, bool COOP, int MAXW>
-__global__ void __launch_bounds__(64 * MAXW) gpfq_slab_dma_kernel(const SlabParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int NW = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int S = p.S, C = COOP ? p.C : 1;
-    const int P = pow2_ceil(S);
-    int tile, c, g;
-    if (COOP) {
-        g = 0;
-        if ((p.tiles & 7) == 0) {
-            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-            tile = (j / C) * 8 + xcd;
-            c = j % C;
-        } else {
-            tile = blockIdx.x / C;
-            c = blockIdx.x % C;
-        }
-    } else {
-        tile = blockIdx.x; c = 0; g = blockIdx.y;
-    }
-    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
-    const int n_own = seg_hi - seg_lo;
-    const int max_own = (S + C - 1) / C;
-    const int rwave = NW > max_own ? max_own : 0;
-    const bool active = wave < n_own;
-    const int myseg = seg_lo + (active ? wave : 0);
-    const int nl = P / C;
-    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane % nl, nl);
-    const int rlane = lane / nl;
-
-    // LDS: [max_own][2048] staging (x then a, 4 KiB each) | segs[2][RT][NW] | qs[2][RT+1] | wchunk[2][RT+1][64]
-    float* stage = smem + (size_t)(active ? wave : 0) * 2048;
-    float* segs = smem + (size_t)max_own * 2048;
-    float* qs = segs + 2 * RT * NW;
-    float* wchunk = qs + 2 * (RT + 1) + ((2 * RT * NW + 2 * (RT + 1)) & 1);   // keep it 8-byte aligned (cosmetic)
-
-    const int row0 = tile * RT;
-    const int64_t grow0 = (int64_t)g * p.Ng + row0;
-    const int64_t kbase = (int64_t)myseg * kSeg + 4 * lane;
-    const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
-    const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
-    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
-
-    float u[RT][16];
-    const float* __restrict__ wrow[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
-        wrow[r] = p.W + gr * p.ldw;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
-    }
-    // chunk 0 of the per-step scalars: wchunk[0][r][l] = W[row r][l], wchunk[0][RT][l] = nrm2[l]
-    for (int i = threadIdx.x; i < (RT + 1) * 64; i += blockDim.x) {
-        const int r = i >> 6, l = i & 63;
-        float val = 0.0f;
-        if (l < p.d) val = (r < RT) ? wrow[r < RT ? r : 0][l] : nrm[l];
-        wchunk[r * 64 + l] = val;
-    }
-    float qprev[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) qprev[r] = 0.0f;
-
-    // xc = x_t, xo = x_{t-1} (zero at t = 0, where q_{-1} = 0), aa = a_t
-    float xc[16], xo[16], aa[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { xc[e] = 0.0f; xo[e] = 0.0f; aa[e] = 0.0f; }
-    // column index the next DMA fetches (clamped to the last column: a harmless re-read at the end)
-    int col_next = 0;
-    if (active) {
-        dma_column(xcol, stage);
-        dma_column(acol, stage + 1024);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        read_staged(xc, stage, lane);
-        read_staged(aa, stage + 1024, lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        col_next = p.d > 1 ? 1 : 0;
-        dma_column(xcol + (int64_t)col_next * p.m_pad, stage);
-        dma_column(acol + (int64_t)col_next * p.m_pad, stage + 1024);
-    }
-    wg_barrier();                                    // wchunk[0] visible
-
-    bool dead = false;
-    for (int t = 0; t < p.d && !dead; ++t) {
-        const int par = t & 1;
-        float* seg = segs + par * RT * NW;
-        const float* wc = wchunk + ((t >> 6) & 1) * (RT + 1) * 64 + (t & 63);
-        if (active) {
-            float acc[RT];
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wc[r * 64]);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                const float sg = wave_tree64(acc[r]);
-                if (lane == 0) seg[r * NW + wave] = sg;
-            }
-        }
-        wg_barrier();
-        // off the critical path: column t+1 from the staging area into registers, then re-arm the DMA with t+2
-        auto restage = [&]() {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) xo[e] = xc[e];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_staged(xc, stage, lane);
-            read_staged(aa, stage + 1024, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            col_next = col_next + 1 < p.d ? col_next + 1 : col_next;
-            dma_column(xcol + (int64_t)col_next * p.m_pad, stage);
-            dma_column(acol + (int64_t)col_next * p.m_pad, stage + 1024);
-        };
-        if (active && wave != rwave) restage();
-        if (wave == rwave) {
-            reducer_section<RT, MODE, COOP>(p, seg, qs, smap, NW, nl, rlane, lane, tile, c, C, par, t, wc[RT * 64], row0,
-                                            grow0, seg_lo);
-            // refill the other half of the scalar chunk buffer one step before it is needed
-            if ((t & 63) == 63 && t + 1 < p.d) {
-                float* wn = wchunk + (((t + 1) >> 6) & 1) * (RT + 1) * 64;
-                const int tt = t + 1 + lane;
-#pragma unroll
-                for (int r = 0; r < RT; ++r) wn[r * 64 + lane] = tt < p.d ? wrow[r][tt] : 0.0f;
-                wn[RT * 64 + lane] = tt < p.d ? nrm[tt] : 0.0f;
-            }
-        }
-        if (active && wave == rwave) restage();
-        wg_barrier();
-#pragma unroll
-        for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
-        if (COOP) dead = qs[par * (RT + 1) + RT] != 0.0f;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the last (unused) DMA before the LDS goes away
-    if (dead || !active) return;
-
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float pq = qprev[r] * xo[e];       // xo = x_{d-1} after the last rotation
-            u[r][e] = u[r][e] - pq;
-        }
-        if (row0 + r < p.Ng) {
-            float* Urow = p.U + (grow0 + r) * p.ldu;
-            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
-            else store_u16<false>(u[r], Urow, kbase, p.m);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Streaming plan: any (N, m).  The residual rows stay in the caller's U (HBM / L2 / Infinity Cache) and
 // are read and written once per step; wave w owns segments w, w+NW, ... of the workgroup's RT rows.
 // ------------------------------------------------------------------------------------------------
@@ -890,11 +701,7 @@ int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* 
     // one more wave for the reducer role when the variant's register budget allows it
     const int nwaves = pl.waves + ((pl.waves + 1 <= MAXW && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
     const int threads = 64 * nwaves;
-    // LDS-DMA column staging (8 KiB per sweep wave) unless disabled or too big for two workgroups' worth of LDS
-    const size_t shm_plain = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1));
-    const size_t shm_dma = shm_plain + sizeof(float) * ((size_t)pl.waves * 2048 + 2 * (RT + 1) * 64 + 2);
-    const bool use_dma = !env_int("GPFQ_NO_DMA", 0) && shm_dma <= 120 * 1024;
-    const size_t shm = use_dma ? shm_dma : shm_plain;
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1));
     hipError_t e;
     dim3 grid;
     if (COOP) {
@@ -903,8 +710,7 @@ int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* 
         // known to over-report by one only near the SGPR limit of >= 6 waves per SIMD; these kernels run at
         // <= 4, so the answer is taken as is -- and every spin is bounded anyway)
         int nb = 0;
-        e = use_dma ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_dma_kernel<RT, MODE, COOP, MAXW>, threads, shm)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>, threads, shm);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>, threads, shm);
         if (e != hipSuccess) return hip_fail(e, "occupancy query");
         const int cus = device_cu_count();
         const int need = (nblocks + cus - 1) / cus;
@@ -919,8 +725,7 @@ int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* 
     } else {
         grid = dim3((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
     }
-    if (use_dma) hipLaunchKernelGGL((gpfq::gpfq_slab_dma_kernel<RT, MODE, COOP, MAXW>), grid, dim3((unsigned)threads), shm, st, sp);
-    else hipLaunchKernelGGL((gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>), grid, dim3((unsigned)threads), shm, st, sp);
+    hipLaunchKernelGGL((gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>), grid, dim3((unsigned)threads), shm, st, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ slab kernel launch");
     return GPFQ_OK;
