@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 stream, 2 resident (debug)")
     ap.add_argument("--layers", default=None, help="substring filter on layer names (debug)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,13 +123,18 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from quantized_neural_nets_amd import StepAlgorithm, _lib, dist as qdist
     import torch.distributed as td
     if world > 1:
-        td.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group(args.backend)
         qdist.enable()
     StepAlgorithm.plan = args.plan
 
@@ -184,7 +191,7 @@ def main():
     elapsed = time.perf_counter() - t0
     cur["on"] = False
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -89,6 +89,11 @@ def _all_gather_rows(ctx, local, chunk_rows):
         pad = torch.zeros((chunk_rows - local.shape[0], d), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
     local = local.contiguous()
+    if local.is_cuda and td.get_backend(ctx.group) == "gloo":
+        # rehearsal set-up (several ranks sharing one card, gloo): stage the collective through the host
+        host = torch.empty((ctx.world * chunk_rows, d), dtype=local.dtype)
+        td.all_gather_into_tensor(host, local.cpu(), group=ctx.group)
+        return host.to(local.device)
     out = torch.empty((ctx.world * chunk_rows, d), dtype=local.dtype, device=local.device)
     td.all_gather_into_tensor(out, local, group=ctx.group)
     return out
@@ -150,7 +155,12 @@ def sharded_error_metrics(ctx, W, A, U_loc, groups, rows):
                 AW = A3[:, g, :] @ W[sel].T
                 asq[sel] = (AW.double() ** 2).sum(0).float()
     both = torch.stack([usq, asq])
-    td.all_reduce(both, group=ctx.group)
+    if both.is_cuda and td.get_backend(ctx.group) == "gloo":
+        host = both.cpu()
+        td.all_reduce(host, group=ctx.group)
+        both = host.to(both.device)
+    else:
+        td.all_reduce(both, group=ctx.group)
     usq, asq = both[0], both[1]
     if groups == 1:
         quantize_error = usq.sum().sqrt()
