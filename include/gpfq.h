@@ -148,6 +148,25 @@ int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, f
                        const float* uniform, float* out, int32_t* idx, void* stream);
 
 /*
+ * nrm2[t] = ||column t||_2 ** 2 of columns that are already in the prepared layout XT [D][m_pad]
+ * (step_algorithm.py:142), canonical reduction order -- the norm half of gpfq_prepare_columns_f32.
+ */
+int gpfq_column_norms_f32(const float* XT, int64_t D, int64_t m, int64_t m_pad, float* nrm2, void* stream);
+
+/*
+ * Fused activation capture for Conv2d layers -- replaces SaveInputConv2d.__call__'s unfold / transpose /
+ * reshape / index (quantize_neural_net.py:334-347) AND the transpose of gpfq_prepare_columns_f32: the sampled
+ * kernel-sized patches of an NCHW feature map are written directly in the prepared column layout.
+ *   x            [B][C][H][W] contiguous fp32
+ *   patch_index  [m] int64, the reference's rand_indices: b*L + l with L = Lh*Lw blocks per image; blocks lie
+ *                on a grid whose stride is the kernel size (nn.Unfold(kernel, dilation, padding, kernel), :320)
+ *   outT         [C*kh*kw][m_pad]: row f = (c, i, j) channel-major, column k = patch k; zero for k >= m
+ */
+int gpfq_gather_patches_f32(const float* x, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int pad_h,
+                            int pad_w, int dil_h, int dil_w, const int64_t* patch_index, int64_t m, float* outT,
+                            int64_t m_pad, void* stream);
+
+/*
  * Row statistic for the alphabet radius, percentile == 1 only: rowmax[i] = max_j |W[i][j]|
  * (torch.quantile(|W|, 1, axis=1), step_algorithm.py:191).
  */

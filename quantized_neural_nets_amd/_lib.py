@@ -20,7 +20,7 @@ EXPORTS = [
     "gpfq_abi_version", "gpfq_last_error", "gpfq_padded_m", "gpfq_workspace_bytes",
     "gpfq_prepare_columns_f32", "gpfq_quantization_f32", "gpfq_quantize_layer_f32", "gpfq_quantizer_f32",
     "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32", "gpfq_scratch_bytes",
-    "gpfq_read_status",
+    "gpfq_read_status", "gpfq_column_norms_f32", "gpfq_gather_patches_f32",
 ]
 
 
@@ -63,6 +63,10 @@ def _load():
     lib.gpfq_quantize_groups_prepared_f32.restype = i32
     lib.gpfq_quantize_groups_prepared_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, i32, i32,
                                                       f32, u64, u64, vp, i32, i32, vp, sz, vp]
+    lib.gpfq_column_norms_f32.restype = i32
+    lib.gpfq_column_norms_f32.argtypes = [vp, i64, i64, i64, vp, vp]
+    lib.gpfq_gather_patches_f32.restype = i32
+    lib.gpfq_gather_patches_f32.argtypes = [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, vp]
     lib.gpfq_scratch_bytes.restype = sz
     lib.gpfq_read_status.restype = i32
     lib.gpfq_read_status.argtypes = [vp, c.POINTER(c.c_int), vp]

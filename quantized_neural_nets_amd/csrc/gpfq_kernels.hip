@@ -491,6 +491,40 @@ __global__ void __launch_bounds__(256) gpfq_colnorm_kernel(const float* __restri
     }
 }
 
+// Activation capture for Conv2d layers, fused: the sampled kernel-sized patches of an NCHW feature map go
+// straight into the transposed, zero-padded column layout the loop kernels read (row f = feature (c, i, j),
+// channel-major; column k = sampled patch k).  Patches sit on a grid whose stride is the KERNEL SIZE, as the
+// reference's nn.Unfold(kernel_size, dilation, padding, kernel_size) does (quantize_neural_net.py:320).
+// Replaces unfold + transpose + reshape + index (quantize_neural_net.py:334-347) and gpfq_transpose_pad_kernel.
+// blockDim = 256: 64 patches x 4 feature lanes; grid = (m_pad / 64, ceil(D / 64)).
+__global__ void __launch_bounds__(256) gpfq_gather_patches_kernel(const float* __restrict__ x, int C, int H, int W,
+                                                                  int kh, int kw, int ph, int pw, int dh, int dw,
+                                                                  int Lw, int64_t L, const int64_t* __restrict__ patch,
+                                                                  int64_t m, float* __restrict__ outT, int64_t m_pad, int D)
+{
+    const int kx = threadIdx.x & 63, fy = threadIdx.x >> 6;
+    const int64_t k = (int64_t)blockIdx.x * 64 + kx;
+    const bool live = k < m;
+    int64_t b = 0;
+    int y0 = 0, x0 = 0;
+    if (live) {
+        const int64_t pi = patch[k];
+        b = pi / L;
+        const int l = (int)(pi - b * L);
+        y0 = (l / Lw) * kh - ph;
+        x0 = (l % Lw) * kw - pw;
+    }
+    const float* __restrict__ img = x + b * (int64_t)C * H * W;
+    const int f_end = min(D, (int)(blockIdx.y + 1) * 64);
+    for (int f = blockIdx.y * 64 + fy; f < f_end; f += 4) {
+        const int c = f / (kh * kw), r = f - c * (kh * kw);
+        const int yy = y0 + (r / kw) * dh, xx = x0 + (r % kw) * dw;
+        float v = 0.0f;
+        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((int64_t)c * H + yy) * W + xx];
+        outT[(int64_t)f * m_pad + k] = v;
+    }
+}
+
 __global__ void gpfq_quantizer_kernel(int mode, float step, const float* __restrict__ x, int64_t n, float Kf,
                                       float lamb, const float* __restrict__ uniform, float* __restrict__ out,
                                       int32_t* __restrict__ idx)
@@ -964,6 +998,43 @@ int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, f
                        (hipStream_t)stream, mode, step, x, n, (float)K, lamb, uniform, out, idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "quantizer launch");
+    return GPFQ_OK;
+}
+
+int gpfq_column_norms_f32(const float* XT, int64_t D, int64_t m, int64_t m_pad, float* nrm2, void* stream)
+{
+    if (!XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (D < 0 || m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "bad shape (m_pad must equal gpfq_padded_m(m))");
+    if (D == 0) return GPFQ_OK;
+    const int S = (int)(m_pad / gpfq::kSeg);
+    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(256), sizeof(float) * (size_t)S,
+                       (hipStream_t)stream, XT, m_pad, S, nrm2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "colnorm launch");
+    return GPFQ_OK;
+}
+
+int gpfq_gather_patches_f32(const float* x, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int pad_h,
+                            int pad_w, int dil_h, int dil_w, const int64_t* patch_index, int64_t m, float* outT,
+                            int64_t m_pad, void* stream)
+{
+    if (!x || !outT || (!patch_index && m > 0)) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (B < 1 || C < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || dil_h < 1 || dil_w < 1 || pad_h < 0 || pad_w < 0 || m < 0)
+        return fail(GPFQ_ERR_ARG, "bad shape");
+    if (m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "m_pad must equal gpfq_padded_m(m)");
+    // nn.Unfold(kernel, dilation, padding, stride = kernel): blocks per axis
+    const int64_t Lh = (H + 2 * pad_h - (int64_t)dil_h * (kh - 1) - 1) / kh + 1;
+    const int64_t Lw = (W + 2 * pad_w - (int64_t)dil_w * (kw - 1) - 1) / kw + 1;
+    if (Lh < 1 || Lw < 1) return fail(GPFQ_ERR_ARG, "kernel larger than the padded input");
+    const int64_t D = C * kh * kw;
+    if (D > 0x7fffffff || C * H * W > 0x7fffffffffffLL) return fail(GPFQ_ERR_UNSUPPORTED, "feature map too large");
+    dim3 grid((unsigned)(m_pad / 64), (unsigned)((D + 63) / 64), 1);
+    if (grid.y > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "too many features");
+    hipLaunchKernelGGL(gpfq::gpfq_gather_patches_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (int)C, (int)H, (int)W,
+                       kh, kw, pad_h, pad_w, dil_h, dil_w, (int)Lw, Lh * Lw, patch_index, m, outT, m_pad, (int)D);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gather_patches launch");
+    (void)B;
     return GPFQ_OK;
 }
 

@@ -99,6 +99,11 @@ def _all_gather_rows(ctx, local, chunk_rows):
     return out
 
 
+def _col_slice(M, lo, hi):
+    """columns [lo, hi) of a layer input: an (m, D) matrix or a PreparedColumns (which slices rows of its T)"""
+    return M.cols(lo, hi) if hasattr(M, "cols") else M[:, lo:hi]
+
+
 def quantize_sharded(ctx, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb, idx_dtype, run_rows):
     """Quantize this rank's neurons and gather the indices of all ranks.
     run_rows(W_loc, groups_loc, A_loc, lda, X_loc, ldx, row_id0) -> (Q_loc, idx_loc, U_loc).
@@ -114,8 +119,8 @@ def quantize_sharded(ctx, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb, id
         gathered = _all_gather_rows(ctx, idx_loc, chunk)[:N]
     elif kind == "groups":
         rows = torch.arange(a * Ng, b * Ng, device=dev)
-        A_loc = A[:, a * dg:max(b, a) * dg] if b > a else A[:, :0]
-        X_loc = X[:, a * dg:max(b, a) * dg] if b > a else X[:, :0]
+        A_loc = _col_slice(A, a * dg, max(b, a) * dg if b > a else a * dg)
+        X_loc = _col_slice(X, a * dg, max(b, a) * dg if b > a else a * dg)
         _, idx_loc, U_loc = run_rows(W[a * Ng:b * Ng], max(b - a, 1), A_loc, lda, X_loc, ldx, a * Ng)
         gathered = _all_gather_rows(ctx, idx_loc, chunk * Ng)[:N]
     else:
@@ -135,6 +140,8 @@ def quantize_sharded(ctx, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb, id
 
 def sharded_error_metrics(ctx, W, A, U_loc, groups, rows):
     """step_algorithm.py:216-219 / :239-243 from per-rank partial sums of squares."""
+    if hasattr(A, "matrix"):
+        A = A.matrix()
     N, dg = W.shape
     mm = A.shape[0]
     dev = W.device

@@ -17,7 +17,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .step_algorithm import StepAlgorithm
+import ctypes
+
+from . import _lib
+from .step_algorithm import PreparedColumns, StepAlgorithm
 from .utils import InterruptException, extract_layers
 
 LINEAR_MODULE_TYPE = nn.Linear
@@ -25,6 +28,9 @@ CONV2D_MODULE_TYPE = nn.Conv2d
 
 RESULT_LOGGING_DIR = 'result_logging'
 LAYER_LOGGING = False
+# Conv2d capture: gather the sampled patches on the GPU straight into the kernels' column layout
+# (gpfq_gather_patches_f32) instead of materialising the full unfold and transposing it afterwards.
+FUSED_CAPTURE = True
 
 
 class QuantizeNeuralNet:
@@ -154,6 +160,10 @@ class QuantizeNeuralNet:
         return (save_input.inputs[0], save_input.inputs[1])
 
 
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
 class SaveInputMLP:
     '''Forward hook that records the input of a Linear layer and aborts the forward
     (quantize_neural_net.py:277-292).'''
@@ -186,15 +196,30 @@ class SaveInputConv2d:
         if len(module_in) != 1:
             raise TypeError('The number of input layer is not equal to one!')
         x = module_in[0]                                               # (B, C, H, W)
-        cols = F.unfold(x, self.kernel_size, dilation=self.dilation, padding=self.padding,
-                        stride=self.kernel_size)                       # (B, C*kh*kw, L)
-        B, L = cols.shape[0], cols.shape[-1]
+        B, C, H, W = x.shape
+        kh, kw = _pair(self.kernel_size)
+        ph, pw = _pair(self.padding)
+        dh, dw = _pair(self.dilation)
+        # blocks per image of nn.Unfold(kernel, dilation, padding, stride = kernel)
+        L = ((H + 2 * ph - dh * (kh - 1) - 1) // kh + 1) * ((W + 2 * pw - dw * (kw - 1) - 1) // kw + 1)
         if self.call_count == 0:
             keep = int(self.p * L + 1 if self.p != 1 else self.p * L)
             # same generator consumption as np.random.choice(np.arange(L*i, L*(i+1)), size=keep), i = 0..B-1
             self.rand_indices = np.concatenate([L * i + np.random.choice(L, size=keep) for i in range(B)])
         self.call_count += 1
-        rows = cols.transpose(1, 2).reshape(B * L, -1)                 # (B*L, C*kh*kw)
-        sel = torch.as_tensor(self.rand_indices, device=rows.device, dtype=torch.long)
-        self.inputs.append(rows.index_select(0, sel))
+        sel = torch.as_tensor(self.rand_indices, device=x.device, dtype=torch.long)
+        if FUSED_CAPTURE and x.is_cuda and x.dtype == torch.float32:
+            m = sel.numel()
+            mp = _lib.lib.gpfq_padded_m(m)
+            xc = x.contiguous()
+            T = torch.empty((C * kh * kw, mp), device=x.device, dtype=torch.float32)
+            _lib.check(_lib.lib.gpfq_gather_patches_f32(
+                ctypes.c_void_p(xc.data_ptr()), B, C, H, W, kh, kw, ph, pw, dh, dw, ctypes.c_void_p(sel.data_ptr()), m,
+                ctypes.c_void_p(T.data_ptr()), mp, _lib.current_stream_ptr(x.device)))
+            self.inputs.append(PreparedColumns(T, m))
+        else:
+            cols = F.unfold(x, self.kernel_size, dilation=self.dilation, padding=self.padding,
+                            stride=self.kernel_size)                   # (B, C*kh*kw, L)
+            rows = cols.transpose(1, 2).reshape(B * L, -1)             # (B*L, C*kh*kw)
+            self.inputs.append(rows.index_select(0, sel))
         raise InterruptException

@@ -43,6 +43,30 @@ def _rows_view(t, name):
     return t, max(ld, t.shape[1], 1)
 
 
+class PreparedColumns:
+    """A layer input already in the kernels' column layout: T is (D, m_pad) fp32 on the GPU, row f = input
+    feature f, column k = calibration sample k, zero for k >= m (include/gpfq.h gpfq_prepare_columns_f32).
+    Produced by the fused conv capture (gpfq_gather_patches_f32); accepted by StepAlgorithm._quantize_layer in
+    place of the (m, D) matrix, whose `.shape` / `.matrix()` it still offers."""
+
+    def __init__(self, T, m):
+        self.T, self.m = T, int(m)
+
+    @property
+    def shape(self):
+        return (self.m, self.T.shape[0])
+
+    @property
+    def device(self):
+        return self.T.device
+
+    def matrix(self):
+        return self.T[:, :self.m].T
+
+    def cols(self, lo, hi):
+        return PreparedColumns(self.T[lo:hi], self.m)
+
+
 def _idx_dtype(K):
     return (torch.int8, 1) if K <= 126 else (torch.int16, 2)
 
@@ -160,16 +184,25 @@ class StepAlgorithm:
         When neuron sharding is enabled (dist.enable) W's rows are split over the ranks, the index shards are
         all-gathered (one RCCL all_gather per layer) and Q is rebuilt locally; U stays sharded.'''
         _lib.require_gpu_tensor(W, "W")
-        _lib.require_gpu_tensor(analog_layer_input, "analog_layer_input")
-        _lib.require_gpu_tensor(quantized_layer_input, "quantized_layer_input")
         if W.dim() != 2:
             raise _lib.GpfqError("W must be (N, d)")
         W = W.contiguous()
         N, dg = W.shape
-        A, lda = _rows_view(analog_layer_input, "analog_layer_input")
-        X, ldx = _rows_view(quantized_layer_input, "quantized_layer_input")
+        prepared = isinstance(analog_layer_input, PreparedColumns)
+        if prepared != isinstance(quantized_layer_input, PreparedColumns):
+            raise _lib.GpfqError("both layer inputs must be matrices or both PreparedColumns")
+        if prepared:
+            A, X = analog_layer_input, quantized_layer_input
+            _lib.require_gpu_tensor(A.T, "analog_layer_input")
+            _lib.require_gpu_tensor(X.T, "quantized_layer_input")
+            lda = ldx = 0
+        else:
+            _lib.require_gpu_tensor(analog_layer_input, "analog_layer_input")
+            _lib.require_gpu_tensor(quantized_layer_input, "quantized_layer_input")
+            A, lda = _rows_view(analog_layer_input, "analog_layer_input")
+            X, ldx = _rows_view(quantized_layer_input, "quantized_layer_input")
         mm = A.shape[0]
-        if A.shape != (mm, groups * dg) or X.shape != A.shape:
+        if tuple(A.shape) != (mm, groups * dg) or tuple(X.shape) != tuple(A.shape):
             raise _lib.GpfqError("layer inputs must be (m, groups*d): got %s / %s for W %s groups %d" % (
                 tuple(A.shape), tuple(X.shape), tuple(W.shape), groups))
         if N % groups != 0:
@@ -208,14 +241,21 @@ class StepAlgorithm:
             # bracket the column preparation and the loop kernel with events on the current stream
             D = groups_loc * dg
             mp = _lib.lib.gpfq_padded_m(mm)
-            AT = torch.empty((D, mp), device=dev, dtype=torch.float32)
-            XT = torch.empty((D, mp), device=dev, dtype=torch.float32)
             nrm2 = torch.empty((D,), device=dev, dtype=torch.float32)
             hook = StepAlgorithm.event_hook
             if hook:
                 hook("prepare_begin", (Nl, dg, mm, groups_loc))
-            _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A_loc), lda_loc, _ptr(X_loc), ldx_loc, mm, D,
-                                                         _ptr(AT), _ptr(XT), _ptr(nrm2), mp, st))
+            if prepared:
+                # columns came out of the capture kernel already transposed and padded: only the norms are missing
+                AT, XT = A_loc.T, X_loc.T
+                if not (AT.is_contiguous() and XT.is_contiguous() and AT.shape == (D, mp)):
+                    raise _lib.GpfqError("PreparedColumns must be contiguous (D, m_pad)")
+                _lib.check(_lib.lib.gpfq_column_norms_f32(_ptr(XT), D, mm, mp, _ptr(nrm2), st))
+            else:
+                AT = torch.empty((D, mp), device=dev, dtype=torch.float32)
+                XT = torch.empty((D, mp), device=dev, dtype=torch.float32)
+                _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A_loc), lda_loc, _ptr(X_loc), ldx_loc, mm, D,
+                                                             _ptr(AT), _ptr(XT), _ptr(nrm2), mp, st))
             if hook:
                 hook("loop_begin", (Nl, dg, mm, groups_loc))
             _lib.check(_lib.lib.gpfq_quantize_groups_prepared_f32(
@@ -242,6 +282,8 @@ class StepAlgorithm:
     def _error_metrics(W, A, U, groups, rows, shard):
         '''step_algorithm.py:216-219 (groups == 1) and :239-243 (mean over groups of per-group norms).
         A @ W.T is one MFMA GEMM (torch.matmul -> hipBLASLt), computed once instead of twice.'''
+        if isinstance(A, PreparedColumns):
+            A = A.matrix()
         N, dg = W.shape
         mm = A.shape[0]
         if shard is not None:

@@ -60,3 +60,59 @@ def test_ignore_layers_and_unsupported_layer_type():
     assert not torch.equal(quant.quantized_network_layers[1].weight, quant.analog_network_layers[1].weight)
     w = quant.quantized_network_layers[4].weight
     assert torch.unique(w).numel() <= 17
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, C, H, W, kernel, padding, dilation, retain
+    (5, 4, 12, 12, 3, 1, 1, 0.25),
+    (3, 6, 14, 10, (3, 2), (1, 0), 1, 0.5),
+    (4, 3, 17, 17, 7, 3, 1, 0.25),
+    (2, 8, 9, 9, 1, 0, 1, 1),
+    (3, 5, 16, 16, 3, 2, 2, 0.3),
+    (2, 70, 8, 8, 5, 2, 1, 0.25),        # more than 64 features per patch column block
+])
+def test_fused_capture_equals_unfold_path(cfg):
+    """gpfq_gather_patches_f32 (patches straight into the column layout) == unfold -> transpose -> reshape -> index
+    (quantize_neural_net.py:334-347), bit for bit, including the zero padding of the columns."""
+    import quantized_neural_nets_amd.quantize_neural_net as qnn
+    from quantized_neural_nets_amd.step_algorithm import PreparedColumns
+    from quantized_neural_nets_amd.utils import InterruptException
+    B, C, H, W, k, pad, dil, retain = cfg
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    outs = {}
+    for fused in (True, False):
+        qnn.FUSED_CAPTURE = fused
+        np.random.seed(123)
+        hook = qnn.SaveInputConv2d(kernel_size=k, dilation=dil, padding=pad, stride=1, groups=1, retain_rate=retain)
+        for xin in (x, x * 2.0):
+            with pytest.raises(InterruptException):
+                hook(None, (xin,), None)
+        outs[fused] = hook.inputs
+    qnn.FUSED_CAPTURE = True
+    for a, b in zip(outs[True], outs[False]):
+        assert isinstance(a, PreparedColumns) and tuple(a.shape) == tuple(b.shape)
+        assert torch.equal(a.matrix(), b)
+        assert a.T.shape[1] % 1024 == 0 and float(a.T[:, a.m:].abs().sum()) == 0.0
+
+
+def test_driver_matches_reference_without_fused_capture():
+    import quantized_neural_nets_amd.quantize_neural_net as qnn
+    qnn.FUSED_CAPTURE = False
+    try:
+        fx = np.load(os.path.join(gi.GOLDEN_DIR, "g5_driver.npz"))
+        meta = json.loads(str(fx["meta"]))["configs"][0]
+        cfg = meta["cfg"]
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(meta["net_seed"])
+        net = gi.toy_net(rng).to(dev)
+        batches = gi.toy_batches(rng, meta["batch"], meta["nlayers"])
+        np.random.seed(meta["np_seed"])
+        quant = qnn.QuantizeNeuralNet(net, "toy", meta["batch"], batches, cfg["bits"], cfg["bits"], [], 1.16, 1.16, 1, 1,
+                                      cfg["reg"], cfg["lamb"], cfg["retain_rate"], False, dev)
+        quant.quantize_network()
+        for li, layer in enumerate(quant.quantized_network_layers):
+            assert np.array_equal(layer.weight.detach().cpu().numpy(), fx["c0_layer%d_weight" % li])
+    finally:
+        qnn.FUSED_CAPTURE = True
