@@ -190,6 +190,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     cur["on"] = False
+    _lib.check_status(dev)          # a cooperative kernel that gave up waiting for a peer invalidates the run
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)

@@ -163,11 +163,30 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
     int id;
     const float q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
     if (lead) qs[par * (RT + 1) + gr_] = q;
-    if (rvalid && c == 0) {
-        p.Q[growl * p.ldq + t] = q;
-        if (p.idx) {
-            if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[growl * p.ldi + t] = (int8_t)id;
-            else reinterpret_cast<int16_t*>(p.idx)[growl * p.ldi + t] = (int16_t)id;
+    // Q / idx leave through a 64-step history in LDS and one coalesced store per row every 64 steps: a
+    // store per step would queue behind the sweep waves' column loads in the vector-memory pipe and hold up
+    // the reducer's arrival at the second barrier.
+    float* hist = qs + 2 * (RT + 1);                 // [RT][64] values, then [RT][64] indices (as int bits)
+    if (lead) {
+        hist[gr_ * 64 + (t & 63)] = q;
+        hist[(RT + gr_) * 64 + (t & 63)] = __int_as_float(id);
+    }
+    if ((t & 63) == 63 || t + 1 == p.d) {
+        const int t0 = t & ~63;
+        const int n = t - t0 + 1;                    // steps in this history block
+        if (c == 0 && lane < n) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (row0 + r < p.Ng) {
+                    const int64_t gw = grow0 + r;
+                    p.Q[gw * p.ldq + t0 + lane] = hist[r * 64 + lane];
+                    if (p.idx) {
+                        const int iv = __float_as_int(hist[(RT + r) * 64 + lane]);
+                        if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)iv;
+                        else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)iv;
+                    }
+                }
+            }
         }
     }
     if (COOP && lane == 0) {
@@ -220,7 +239,7 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
     const int rlane = lane / nl;                    // row whose slot this lane holds (>= RT: idle)
 
     float* segs = smem;                             // [2][RT][NW]
-    float* qs = smem + 2 * RT * NW;                 // [2][RT + 1]   (last = abort flag)
+    float* qs = smem + 2 * RT * NW;                 // [2][RT + 1] (last = abort flag), then the Q / idx history [2*RT][64]
 
     const int row0 = tile * RT;                     // row inside the group
     const int64_t grow0 = (int64_t)g * p.Ng + row0; // global row of this tile's first row
@@ -735,7 +754,7 @@ int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* 
     // one more wave for the reducer role when the variant's register budget allows it
     const int nwaves = pl.waves + ((pl.waves + 1 <= MAXW && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
     const int threads = 64 * nwaves;
-    const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1));
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1) + 2 * RT * 64);
     hipError_t e;
     dim3 grid;
     if (COOP) {
