@@ -57,6 +57,26 @@ __device__ __forceinline__ float wave_tree64(float v)
     return v;
 }
 
+// Same tree, total delivered in lane 63 only, all six levels as DPP adds (no permlane swap, no extra moves):
+// after the four in-row levels every lane of a row holds its row sum; row_bcast15 adds lane 15 of the previous
+// row into rows 1 and 3 (r1+r0, r3+r2), row_bcast31 adds lane 31 (= r1+r0) into rows 2 and 3, so row 3 ends with
+// (r3+r2)+(r1+r0): the canonical tree up to operand order.  Disabled rows add the +0.0f of `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_rows(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_tree64_lane63(float v)
+{
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    v = v + dpp_mov_rows<0x142, 0xa>(v);   // row_bcast15 into rows 1, 3
+    v = v + dpp_mov_rows<0x143, 0xc>(v);   // row_bcast31 into rows 2, 3
+    return v;
+}
+
 // The same tree over the first nl lanes only (nl a power of two, wave-uniform): the upper levels, which
 // would add the +0.0f of idle lanes, are skipped (adding +0.0f is exact).  Result valid in lanes < nl.
 __device__ __forceinline__ float wave_tree_n(float v, int nl)

@@ -304,8 +304,8 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
             GPFQ_STAMP(1)
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                const float sg = wave_tree64(acc[r]);
-                if (lane == 0) seg[r * NW + wave] = sg;
+                const float sg = wave_tree64_lane63(acc[r]);
+                if (lane == 63) seg[r * NW + wave] = sg;
             }
             GPFQ_STAMP(2)
         }
@@ -434,8 +434,8 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p)
                 } else {
                     float acc = first ? sweep16<false>(u, xc, ac, xc, 0.0f, w[r])
                                       : sweep16<true>(u, xp, ac, xc, qprev[r], w[r]);
-                    float sg = wave_tree64(acc);
-                    if (lane == 0) seg[r * S + s] = sg;
+                    float sg = wave_tree64_lane63(acc);
+                    if (lane == 63) seg[r * S + s] = sg;
                 }
                 if (valid[r] || RT == 1) store_u16<VEC>(u, Urow, kbase, p.m);
             }
@@ -496,8 +496,8 @@ __global__ void __launch_bounds__(256) gpfq_colnorm_kernel(const float* __restri
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc = __builtin_fmaf(xv[e], xv[e], acc);
-        float sg = wave_tree64(acc);
-        if (lane == 0) seg[s] = sg;
+        float sg = wave_tree64_lane63(acc);
+        if (lane == 63) seg[s] = sg;
     }
     __syncthreads();
     if (wave == 0) {

@@ -154,6 +154,35 @@ def test_cooperative_configurations(qnn, oracle_mod, monkeypatch, rt, c, mode):
     assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
 
 
+@pytest.mark.parametrize("rt", [1, 2, 4])
+def test_resident_rows_per_workgroup_variants(qnn, oracle_mod, monkeypatch, rt):
+    """The resident instantiations with 1 / 2 / 4 rows per workgroup (only RT = 1 is picked automatically)."""
+    N, d, m = 19, 24, 5000                       # 5 segments; 19 rows -> ragged tiles for RT = 2, 4
+    case = dict(name="resrt", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg="L1", lamb=0.01, groups=1,
+                first_layer=False, zero_every=5, seed=4)
+    W, A, X = gi.make_inputs(case)
+    monkeypatch.setenv("GPFQ_RESIDENT_RT", str(rt))
+    from quantized_neural_nets_amd import _lib
+    assert _lib.describe_plan(N, d, m).startswith("resident RT=%d" % rt)
+    r = _run_layer(qnn, case, W, A, X, 0)
+    o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, "L1", 0.01, 1)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+
+
+def test_long_layer_crosses_history_blocks(qnn, oracle_mod):
+    """d > 64 with d % 64 != 0: the Q / idx history is flushed every 64 columns and once more at the end."""
+    case = dict(name="hist", N=6, d=201, m=1500, bits=3, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,
+                first_layer=True, zero_every=0, seed=8)
+    W, A, X = gi.make_inputs(case)
+    for plan in (0, 3):
+        r = _run_layer(qnn, case, W, A, X, plan)
+        o = oracle_mod.quantize_layer(W, A, X, 1.16 / 4, 4, 1.0, None, 0.0, 1)
+        assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+        assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
+        assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+
+
 def test_quantization_in_place_with_initial_residual_and_views(qnn, oracle_mod):
     """StepAlgorithm._quantization mirrors step_algorithm.py:107-148: in place on Q and U, U may be non-zero,
     inputs may be strided group views (:236)."""

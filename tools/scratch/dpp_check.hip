@@ -4,6 +4,11 @@
 __global__ void k(const float* in, float* out, float* out2, float* out3) {
     float v = in[threadIdx.x];
     out[threadIdx.x] = gpfq::wave_tree64(v);
+    {   // lane-63 form: publish lane 63's value to every lane for the comparison below
+        float h = gpfq::wave_tree64_lane63(v);
+        float h63 = __shfl(h, 63, 64);
+        if (h63 != out[threadIdx.x]) out[threadIdx.x] = -12345.0f;
+    }
     float w = v;
     for (int off = 1; off < 64; off <<= 1) w = w + __shfl_xor(w, off, 64);
     out2[threadIdx.x] = w;
