@@ -377,18 +377,50 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
 // Streaming plan: any (N, m).  The residual rows stay in the caller's U (HBM / L2 / Infinity Cache) and
 // are read and written once per step; wave w owns segments w, w+NW, ... of the workgroup's RT rows.
 // ------------------------------------------------------------------------------------------------
-template <int RT, bool VEC>
-__global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p)
+struct StreamCoop {
+    int C;                              // members per row tile (1 = every workgroup owns whole rows)
+    int tiles;                          // row tiles
+    unsigned long long* xbuf;           // exchange granules [tiles][2][C][RT] (C > 1 only)
+    int* status;
+    unsigned spin_limit;
+};
+
+// COOP = false: workgroup (blockIdx.x, blockIdx.y = group) owns RT whole rows.
+// COOP = true : groups == 1; a row tile's columns are split over C workgroups (block -> (tile, member) as in the
+//               slab kernel), each streams its segment range and the per-row partial sums are exchanged per step
+//               with the same granule protocol -- so that few long rows still fill every CU and RT rows share each
+//               column load.
+template <int RT, bool VEC, bool COOP>
+__global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCoop sc)
 {
-    extern __shared__ float smem[];                 // [2][RT][S]
+    extern __shared__ float smem[];                 // seg[2][RT][n_max] | qs[2][RT+1]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int NW = blockDim.x >> 6;
-    const int S = p.S;
+    const int S = p.S, C = COOP ? sc.C : 1;
     const int P = pow2_ceil(S);
-    const int per = P > 64 ? P / 64 : 1, nl = P > 64 ? 64 : P;
-    const SlotMap smap = make_slot_map(S, P, 0, per, lane, nl);
-    const int g = blockIdx.y;
-    const int64_t row0 = (int64_t)blockIdx.x * RT;
+    int tile, c, g;
+    if (COOP) {
+        g = 0;
+        if ((sc.tiles & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            tile = (j / C) * 8 + xcd;
+            c = j % C;
+        } else {
+            tile = blockIdx.x / C;
+            c = blockIdx.x % C;
+        }
+    } else {
+        tile = blockIdx.x; c = 0; g = blockIdx.y;
+    }
+    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
+    const int n_max = (S + C - 1) / C;              // LDS row length (segments of the fullest member)
+    const int bslots = P / C;                       // this member's aligned block of the slot tree
+    const int per = bslots > 64 ? bslots / 64 : 1, nl = bslots > 64 ? 64 : bslots;
+    const SlotMap smap = make_slot_map(S, P, c * bslots, per, lane, nl);
+    float* segs = smem;
+    float* qs = smem + 2 * RT * n_max;
+
+    const int64_t row0 = (int64_t)tile * RT;
     const float* __restrict__ ATg = p.AT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
     const float* __restrict__ XTg = p.XT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
     const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
@@ -403,14 +435,16 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p)
         qprev[r] = 0.0f;
     }
 
-    for (int64_t t = 0; t <= p.d; ++t) {
+    bool dead = false;
+    for (int64_t t = 0; t <= p.d && !dead; ++t) {
         const bool last = (t == p.d);               // extra pass: only the pending subtraction
         const bool first = (t == 0);
+        const int par = (int)(t & 1);
         float w[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) w[r] = last ? 0.0f : p.W[grow[r] * p.ldw + t];
-        float* seg = smem + (size_t)(t & 1) * RT * S;
-        for (int s = wave; s < S; s += NW) {
+        float* seg = segs + (size_t)par * RT * n_max;
+        for (int s = seg_lo + wave; s < seg_hi; s += NW) {
             const int64_t kbase = (int64_t)s * kSeg + 4 * lane;
             float xp[16], xc[16], ac[16];
             if (!first) load16(xp, XTg + (t - 1) * p.m_pad + (int64_t)s * kSeg);
@@ -435,23 +469,68 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p)
                     float acc = first ? sweep16<false>(u, xc, ac, xc, 0.0f, w[r])
                                       : sweep16<true>(u, xp, ac, xc, qprev[r], w[r]);
                     float sg = wave_tree64_lane63(acc);
-                    if (lane == 63) seg[r * S + s] = sg;
+                    if (lane == 63) seg[r * n_max + (s - seg_lo)] = sg;
                 }
                 if (valid[r] || RT == 1) store_u16<VEC>(u, Urow, kbase, p.m);
             }
         }
         if (last) break;
         __syncthreads();
-        const float n2 = nrm[t];
+        if (wave == 0) {
+            // this member's block of the slot tree, row r's value parked in lane r
+            float mine = 0.0f;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            float tot = combine_slots(seg + r * S, smap, per, nl, S - 1);
-            float sv = (n2 > 0.0f) ? tot / n2 : 0.0f;
+            for (int r = 0; r < RT; ++r) {
+                const float pr = combine_slots(seg + r * n_max - seg_lo, smap, per, nl, seg_hi - 1);
+                if (lane == r) mine = pr;
+            }
+            float v = mine;
+            int blk = 1;
+            bool timed_out = false;
+            if (COOP) {
+                const unsigned epoch = (unsigned)t + 1u;
+                unsigned long long* xb_ = sc.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
+                if (lane < RT)
+                    __hip_atomic_store(xb_ + (size_t)c * RT + lane,
+                                       ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(mine),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool want = lane < RT * C;    // gather: lane = r*C + member
+                const unsigned long long* src = xb_ + (want ? (size_t)(lane % C) * RT + (lane / C) : 0);
+                unsigned long long gv = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = !want || ((unsigned)(gv >> 32) == epoch);
+                    if (__all(ok)) break;
+                    if (++spins > sc.spin_limit) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                v = want ? __uint_as_float((unsigned)gv) : 0.0f;
+                v = wave_tree_n(v, C);
+                blk = C;
+            }
+            const int gr_ = lane / blk;
+            const bool lead = (lane % blk == 0) && gr_ < RT;
+            const float n2 = nrm[t];
+            const float sv = (n2 > 0.0f) ? v / n2 : 0.0f;
+            const bool rvalid = lead && (row0 + gr_ < p.Ng);
+            const int64_t growl = (int64_t)g * p.Ng + (rvalid ? row0 + gr_ : p.Ng - 1);
             int id;
-            float q = quantize(p.qc, sv, p.row_id0 + (uint64_t)grow[r], (uint64_t)t, id);
-            qprev[r] = q;
-            if (threadIdx.x == 0 && valid[r]) store_q(p, grow[r], t, q, id);
+            const float q = quantize(p.qc, sv, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
+            if (lead) qs[par * (RT + 1) + gr_] = q;
+            if (rvalid && c == 0) store_q(p, growl, t, q, id);
+            if (lane == 0) {
+                qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
+                if (timed_out) {
+                    atomicExch(sc.status, 1);
+                    sc.status[1] = (int)t; sc.status[2] = tile; sc.status[3] = c;
+                }
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
+        if (COOP) dead = qs[par * (RT + 1) + RT] != 0.0f;
     }
 }
 
@@ -681,6 +760,48 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl)
     return found;
 }
 
+// Streaming configuration.  Whole rows per workgroup when there are enough rows to fill the chip; otherwise
+// (groups == 1, scratch available) the rows' columns are split over C workgroups so that tiles*C covers the CUs
+// and RT rows share every column load.  Depends on (Ng, S, groups, CU count) only.
+void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
+{
+    const int cus = device_cu_count();
+    pl->kind = GPFQ_PLAN_STREAM;
+    pl->S = S;
+    pl->C = 1;
+    pl->RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
+    pl->tiles = (int)((Ng + pl->RT - 1) / pl->RT);
+    pl->waves = S < 8 ? S : 8;
+    if (!allow_coop || groups != 1 || env_int("GPFQ_COOP_DISABLE", 0)) return;
+    const int force_c = env_int("GPFQ_STREAM_C", 0), force_rt = env_int("GPFQ_STREAM_RT", 0);
+    // Measured (tools/layer_bench.py, N = 64..512, m = 51 200..803 840): once 256 workgroups stream, 1, 2 or 4 rows per
+    // workgroup run within 5 % of each other, and whole rows beat the split whenever they already fill the chip.
+    // So: split only if whole-row workgroups cannot cover the CUs; then two rows per workgroup, most workgroups.
+    int best_rt = pl->RT, best_c = 1;
+    int best_score = (pl->tiles >= cus ? cus : pl->tiles) * 8;
+    if (pl->tiles < cus || (force_c && force_rt)) {
+        const int order[3] = {2, 1, 4};
+        for (int k = 0; k < 3; ++k) {
+            const int RT = order[k];
+            if (force_rt && RT != force_rt) continue;
+            const int64_t tiles = (Ng + RT - 1) / RT;
+            if (tiles > cus) continue;
+            for (int C = 64 / RT; C >= 2; C >>= 1) {
+                if (force_c && C != force_c) continue;
+                if (tiles * C > cus || S / C < 8) continue;       // every member keeps >= 8 segments (one per wave)
+                const int score = (int)tiles * C * 8 + (3 - k);
+                if (score > best_score || (force_c && force_rt)) { best_score = score; best_rt = RT; best_c = C; }
+                break;                                             // largest C for this RT
+            }
+        }
+    }
+    if (best_c > 1) {
+        pl->RT = best_rt; pl->C = best_c;
+        pl->tiles = (int)((Ng + best_rt - 1) / best_rt);
+        pl->waves = 8;
+    }
+}
+
 int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, Plan* out)
 {
     Plan pl;
@@ -714,22 +835,49 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
         if (requested == GPFQ_PLAN_COOP)
             return fail(GPFQ_ERR_UNSUPPORTED, "cooperative plan needs groups == 1, a scratch buffer and a shape that fits");
     }
-    pl.kind = GPFQ_PLAN_STREAM;
-    pl.RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
-    pl.waves = pl.S < 8 ? pl.S : 8;
+    choose_stream(Ng, pl.S, groups, have_scratch, &pl);
     *out = pl;
     return GPFQ_OK;
 }
 
 template <int RT>
-hipError_t launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, hipStream_t st)
+int launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, void* scratch, hipStream_t st)
 {
-    dim3 grid((unsigned)((p.Ng + RT - 1) / RT), (unsigned)groups, 1);
+    const int S = p.S;
+    const int C = pl.C > 1 ? pl.C : 1;
+    const int n_max = (S + C - 1) / C;
     dim3 block((unsigned)(64 * pl.waves), 1, 1);
-    size_t shm = sizeof(float) * 2 * RT * (size_t)p.S;
-    if (vec) hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, true>), grid, block, shm, st, p);
-    else hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, false>), grid, block, shm, st, p);
-    return hipGetLastError();
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)n_max + 2 * (RT + 1));
+    gpfq::StreamCoop sc;
+    sc.C = C; sc.tiles = pl.tiles; sc.xbuf = nullptr; sc.status = nullptr;
+    sc.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
+    hipError_t e;
+    if (C > 1) {
+        const int nblocks = pl.tiles * C;
+        int nb = 0;
+        e = vec ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_stream_kernel<RT, true, true>, 64 * pl.waves, shm)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_stream_kernel<RT, false, true>, 64 * pl.waves, shm);
+        if (e != hipSuccess) return hip_fail(e, "occupancy query");
+        const int cus = device_cu_count();
+        if (nb < 1 || (nblocks + cus - 1) / cus > nb) return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
+        size_t xbytes = (size_t)pl.tiles * 2 * C * RT * sizeof(unsigned long long);
+        xbytes = (xbytes + 15) & ~(size_t)15;
+        if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
+        e = hipMemsetAsync(scratch, 0, xbytes, st);
+        if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
+        sc.xbuf = reinterpret_cast<unsigned long long*>(scratch);
+        sc.status = reinterpret_cast<int*>(static_cast<char*>(scratch) + kScratchStatusOffset);
+        dim3 grid((unsigned)nblocks, 1, 1);
+        if (vec) hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, true, true>), grid, block, shm, st, p, sc);
+        else hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, false, true>), grid, block, shm, st, p, sc);
+    } else {
+        dim3 grid((unsigned)((p.Ng + RT - 1) / RT), (unsigned)groups, 1);
+        if (vec) hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, true, false>), grid, block, shm, st, p, sc);
+        else hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, false, false>), grid, block, shm, st, p, sc);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "GPFQ streaming kernel launch");
+    return GPFQ_OK;
 }
 
 gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, bool vec, void* scratch)
@@ -840,18 +988,20 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     if (pl.kind == GPFQ_PLAN_COOP) {
         rc = launch_slab(pl, p, groups, vec, scratch, st);
         if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
-        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, false, &pl);   // does not fit: stream instead
+        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, &pl);   // does not fit: stream instead
         if (rc) return rc;
     }
     if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_slab(pl, p, groups, vec, scratch, st);
-    hipError_t e;
-    switch (pl.RT) {
-    case 4: e = launch_stream<4>(pl, p, groups, vec, st); break;
-    case 2: e = launch_stream<2>(pl, p, groups, vec, st); break;
-    default: e = launch_stream<1>(pl, p, groups, vec, st); break;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        switch (pl.RT) {
+        case 4: rc = launch_stream<4>(pl, p, groups, vec, scratch, st); break;
+        case 2: rc = launch_stream<2>(pl, p, groups, vec, scratch, st); break;
+        default: rc = launch_stream<1>(pl, p, groups, vec, scratch, st); break;
+        }
+        if (rc != GPFQ_ERR_UNSUPPORTED || pl.C <= 1) return rc;
+        choose_stream(p.Ng, pl.S, groups, false, &pl);          // cooperative grid did not fit: whole rows
     }
-    if (e != hipSuccess) return hip_fail(e, "GPFQ loop launch");
-    return GPFQ_OK;
+    return rc;
 }
 
 int check_mode(int mode, int K, int idx_bytes, const void* idx)
@@ -1078,6 +1228,9 @@ int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, 
     if (buf && buf_bytes) {
         if (pl.kind == GPFQ_PLAN_COOP)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
+                     pl.tiles * pl.C, (long long)d_g);
+        else if (pl.kind == GPFQ_PLAN_STREAM && pl.C > 1)
+            snprintf(buf, buf_bytes, "stream RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
                      pl.tiles * pl.C, (long long)d_g);
         else
             snprintf(buf, buf_bytes, "%s RT=%d waves=%d S=%d grid=(%lld,%d) d=%lld",

@@ -170,6 +170,24 @@ def test_resident_rows_per_workgroup_variants(qnn, oracle_mod, monkeypatch, rt):
     assert np.array_equal(r["U"].cpu().numpy(), o["U"])
 
 
+@pytest.mark.parametrize("rt,c", [(1, 2), (2, 4), (4, 2), (4, 8), (1, 16)])
+def test_cooperative_streaming_configurations(qnn, oracle_mod, monkeypatch, rt, c):
+    """Streaming plan with the columns of each row tile split over C workgroups (long rows, few of them)."""
+    N, d, m = 9, 14, 140000                      # 137 segments -> 256 slots; ragged row tiles for RT = 2, 4
+    case = dict(name="scoop", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,
+                first_layer=False, zero_every=5, seed=2)
+    W, A, X = gi.make_inputs(case)
+    monkeypatch.setenv("GPFQ_STREAM_RT", str(rt))
+    monkeypatch.setenv("GPFQ_STREAM_C", str(c))
+    from quantized_neural_nets_amd import _lib
+    assert _lib.describe_plan(N, d, m, 1, 1).startswith("stream RT=%d C=%d" % (rt, c)), _lib.describe_plan(N, d, m, 1, 1)
+    r = _run_layer(qnn, case, W, A, X, 1)
+    _lib.check_status(DEV)
+    o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, None, 0.0, 1)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+
+
 def test_long_layer_crosses_history_blocks(qnn, oracle_mod):
     """d > 64 with d % 64 != 0: the Q / idx history is flushed every 64 columns and once more at the end."""
     case = dict(name="hist", N=6, d=201, m=1500, bits=3, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,
