@@ -38,3 +38,66 @@ def extract_layers(model, layer_list, supported_block_type=None, supported_layer
             extract_layers(layer, layer_list, blocks, leaves)
         if not list(layer.children()) and type(layer) in leaves:
             layer_list.append(layer)
+
+
+# ---- helpers around the path that main.py of the reference imports from utils (main.py:9) -----------------
+def fusion_layers_inplace(model, device):
+    '''Fold every BatchNorm2d that directly follows a Conv2d (in extract_layers order) into the conv weights and
+    leave the BN as "identity plus bias" (utils.py:96-130): w <- w * gamma/sqrt(var+eps); the BN keeps
+    running_mean 0, running_var 1, weight 1 and the folded bias.  The reference sets eps = 0, which current
+    torch rejects ("batch_norm eps must be positive"); 1e-12 is below fp32 resolution next to var = 1, so the
+    arithmetic is the same.'''
+    import torch
+    layers = []
+    extract_layers(model, layers, supported_layer_type=[nn.Conv2d, nn.BatchNorm2d])
+    for conv, bn in zip(layers[:-1], layers[1:]):
+        if not (isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d)):
+            continue
+        inv_std = 1.0 / torch.sqrt(bn.running_var + bn.eps)
+        scale = bn.weight.data * inv_std
+        shift = bn.bias.data - bn.weight.data * bn.running_mean * inv_std
+        conv.weight.data = conv.weight.data * scale[:, None, None, None]
+        n = bn.num_features
+        bn.running_var = torch.ones(n, device=device)
+        bn.running_mean = torch.zeros(n, device=device)
+        bn.weight.data = torch.ones(n, device=device)
+        bn.eps = 1e-12
+        if conv.bias is None:
+            bn.bias.data = shift
+        else:
+            conv.bias.data = conv.bias.data * scale + shift
+            bn.bias.data = torch.zeros(n, device=device)
+
+
+def eval_sparsity(model):
+    '''Fraction of exactly-zero entries among the weights and biases of the quantizable layers, rounded to 4
+    digits (utils.py:133-159).'''
+    import numpy as np
+    layers = []
+    extract_layers(model, layers)
+    total = zeros = 0
+    for layer in layers:
+        for prm in (layer.weight, layer.bias):
+            if prm is not None:
+                total += prm.numel()
+                zeros += int(prm.eq(0).sum().item())
+    return np.around(zeros / total, 4)
+
+
+def test_accuracy(model, test_dl, device, topk=(1, )):
+    '''Top-k accuracy over a loader (utils.py:54-73).'''
+    import numpy as np
+    import torch
+    model.eval()
+    maxk = max(topk)
+    hits = np.zeros(len(topk))
+    for x, target in test_dl:
+        with torch.no_grad():
+            pred = torch.topk(model(x.to(device)), maxk, dim=1).indices
+        match = pred.eq(target.to(device).view(-1, 1))
+        for i, k in enumerate(topk):
+            hits[i] += int(match[:, :k].sum().item())
+    return hits / len(test_dl.dataset)
+
+
+test_accuracy.__test__ = False      # not a pytest test
