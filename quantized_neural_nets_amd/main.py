@@ -1,0 +1,144 @@
+"""Command line of the quantization run -- counterpart of the reference's src/main.py with the same flags
+(main.py:17-41) and the same hyper-parameter grid (main.py:182-193), driving QuantizeNeuralNet on the MI355X.
+
+    python -m quantized_neural_nets_amd.main -model alexnet -b 4 -bs 32 -s 1.16 --synthetic
+
+Models come from torchvision when it is installed (pretrained=True needs its checkpoint cache); without
+torchvision only `alexnet` is available, as a randomly initialised copy of the architecture, which together with
+--synthetic (random calibration batches instead of the ImageNet loader) is enough to run the whole plumbing.
+Dataset evaluation and the CSV log of the reference (main.py:138-177) are only done when a test loader exists.
+"""
+import argparse
+import os
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .quantize_neural_net import QuantizeNeuralNet
+from .utils import eval_sparsity, fusion_layers_inplace, test_accuracy
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='GPFQ post-training quantization (MI355X)')
+    p.add_argument('--bits', '-b', default=[4], type=int, nargs='+', help='number of bits for quantization')
+    p.add_argument('--scalar', '-s', default=[1.16], type=float, nargs='+',
+                   help='the scalar C used to determine the radius of alphabets')
+    p.add_argument('--batch_size', '-bs', default=[128], type=int, nargs='+', help='batch size used for quantization')
+    p.add_argument('--percentile', '-p', default=[1], type=float, nargs='+', help='percentile of weights')
+    p.add_argument('--num_worker', '-w', default=8, type=int, help='number of workers for data loader')
+    p.add_argument('--data_set', '-ds', default='ILSVRC2012', choices=['ILSVRC2012', 'CIFAR10'])
+    p.add_argument('-model', default='resnet18', help='model name')
+    p.add_argument('--stochastic_quantization', '-sq', action='store_true', help='use stochastic quantization')
+    p.add_argument('--retain_rate', '-rr', default=0.25, type=float, help='subsampling probability p for conv layers')
+    p.add_argument('--regularizer', '-reg', default=None, choices=['L0', 'L1'], help='regularization mode')
+    p.add_argument('--lamb', '-l', default=[0.1], type=float, nargs='+', help='regularization term')
+    p.add_argument('--ignore_layer', '-ig', default=[], type=int, nargs='+', help='indices of unquantized layers')
+    p.add_argument('-seed', default=0, type=int, help='set random seed')
+    p.add_argument('--fusion', '-f', action='store_true', help='fusing CNN and BN layers')
+    # additions of this build
+    p.add_argument('--synthetic', action='store_true', help='random calibration batches instead of the dataset loader')
+    p.add_argument('--image_size', default=224, type=int, help='side of the synthetic images')
+    p.add_argument('--save_dir', default=None, help='where to torch.save the quantized model (default: not saved)')
+    return p
+
+
+class AlexNetArch(nn.Sequential):
+    """The AlexNet layer stack (5 convs, 3 fully connected), randomly initialised: stands in for
+    torchvision.models.alexnet when torchvision is not installed."""
+
+    def __init__(self, num_classes=1000):
+        super().__init__(
+            nn.Conv2d(3, 64, 11, stride=4, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(64, 192, 5, padding=2), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2),
+            nn.Conv2d(192, 384, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(384, 256, 3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(inplace=True), nn.MaxPool2d(3, 2),
+            nn.AdaptiveAvgPool2d((6, 6)), nn.Flatten(),
+            nn.Dropout(), nn.Linear(256 * 6 * 6, 4096), nn.ReLU(inplace=True),
+            nn.Dropout(), nn.Linear(4096, 4096), nn.ReLU(inplace=True), nn.Linear(4096, num_classes))
+
+
+def load_model(name):
+    try:
+        import torchvision
+        return getattr(torchvision.models, name)(pretrained=True)
+    except ImportError:
+        if name == 'alexnet':
+            return AlexNetArch()
+        raise SystemExit("torchvision is not installed: only `-model alexnet` (random init) is available")
+
+
+class SyntheticLoader:
+    """Endless (images, labels) batches from a seeded generator -- the loader surface QuantizeNeuralNet needs."""
+
+    def __init__(self, batch_size, image_size, seed):
+        self.bs, self.hw = batch_size, image_size
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __iter__(self):
+        while True:
+            yield torch.randn(self.bs, 3, self.hw, self.hw, generator=self.gen), torch.zeros(self.bs, dtype=torch.long)
+
+
+def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
+    if not torch.cuda.is_available():
+        raise SystemExit("this build runs on the MI355X only (no CPU path)")
+    device = torch.device("cuda:0")
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    model = load_model(args.model).to(device).eval()
+    if args.fusion:
+        fusion_layers_inplace(model, device)
+        print('CNN and BN layers are fused before quantization!\n')
+    mode = ('stochastic quantization, i.e. SGPFQ' if args.stochastic_quantization else
+            f'sparse quantization using {args.regularizer} norm with lambda {lamb}' if args.regularizer else 'GPFQ')
+    print(f'Quantization mode: {mode}')
+    print(f'Quantizing {args.model} on {device}: bits {bits}, mlp_scalar {mlp_s}, cnn_scalar {cnn_s}, '
+          f'percentiles {mlp_per}/{cnn_per}, retain_rate {args.retain_rate}, batch_size {bs}\n')
+    test_loader = None
+    if args.synthetic:
+        train_loader = SyntheticLoader(bs, args.image_size, args.seed)
+    else:
+        try:
+            from data_loaders import data_loader          # the reference's own loader module, if on the path
+        except ImportError:
+            raise SystemExit("no dataset loader available here: use --synthetic")
+        train_loader, test_loader = data_loader(args.data_set, bs, args.num_worker)
+    quantizer = QuantizeNeuralNet(model, args.model, bs, train_loader, mlp_bits=bits, cnn_bits=bits,
+                                  ignore_layers=args.ignore_layer, mlp_alphabet_scalar=mlp_s, cnn_alphabet_scalar=cnn_s,
+                                  mlp_percentile=mlp_per, cnn_percentile=cnn_per, reg=args.regularizer, lamb=lamb,
+                                  retain_rate=args.retain_rate, stochastic_quantization=args.stochastic_quantization,
+                                  device=device)
+    start = datetime.now()
+    quantized_model = quantizer.quantize_network().to(device)
+    torch.cuda.synchronize()
+    print(f'\nTime used for quantization: {datetime.now() - start}\n')
+    if args.save_dir:
+        os.makedirs(os.path.join(args.save_dir, args.model), exist_ok=True)
+        name = (f'ds{args.data_set}_b{bits}_batch{bs}_mlpscalar{mlp_s}_cnnscalar{cnn_s}_mlppercentile{mlp_per}'
+                f'_cnnpercentile{cnn_per}_retain_rate{args.retain_rate}_reg{args.regularizer}_lambda{lamb}.pt')
+        torch.save(quantized_model, os.path.join(args.save_dir, args.model, name))
+    if test_loader is not None:
+        acc = test_accuracy(quantized_model, test_loader, device, (1, 5))
+        print(f'Top-1 / top-5 accuracy of quantized {args.model}: {acc[0]} / {acc[1]}')
+    print("Sparsity: Org: {}, Quant: {}".format(eval_sparsity(model), eval_sparsity(quantized_model)))
+    return quantizer
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    out = None
+    for b in args.bits:                       # the grid of main.py:182-189
+        for s in args.scalar:
+            for bs in args.batch_size:
+                for mlp_per in args.percentile:
+                    for cnn_per in args.percentile:
+                        for lamb in args.lamb:
+                            out = run(args, b, s, s, bs, mlp_per, cnn_per, lamb)
+    return out
+
+
+if __name__ == '__main__':
+    main()

@@ -116,3 +116,22 @@ def test_driver_matches_reference_without_fused_capture():
             assert np.array_equal(layer.weight.detach().cpu().numpy(), fx["c0_layer%d_weight" % li])
     finally:
         qnn.FUSED_CAPTURE = True
+
+
+def test_cli_alexnet_plumbing_config(capsys):
+    """BASELINE.json configs[0] on the GPU: `main.py -model alexnet -b 4 -bs 32 -s 1.16` (random-init AlexNet
+    architecture, synthetic calibration batches): all 8 layers are quantized to the 17-level 4-bit alphabet."""
+    from quantized_neural_nets_amd import main as cli
+    q = cli.main(["-model", "alexnet", "-b", "4", "-bs", "32", "-s", "1.16", "--synthetic"])
+    layers = q.quantized_network_layers
+    assert len(layers) == 8 and len(q.layer_reports) == 8
+    for rep in q.layer_reports:
+        assert np.isfinite(rep["relative_quantize_error"]) and 0 < rep["relative_quantize_error"] < 1.0
+    for layer in (layers[0], layers[4], layers[7]):
+        vals = torch.unique(layer.weight.detach())
+        assert vals.numel() <= 17
+        step = float(vals.detach()[vals.detach() > 0].min())
+        k = vals / step
+        assert torch.allclose(k, torch.round(k), atol=1e-3)
+    out = capsys.readouterr().out
+    assert "Time used for quantization" in out and "Sparsity" in out

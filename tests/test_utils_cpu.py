@@ -27,7 +27,7 @@ def test_fusion_preserves_the_function():
     assert torch.allclose(net(x), want, atol=1e-5)
     bn = net[1]
     assert torch.equal(bn.weight.data, torch.ones(5)) and bn.eps <= 1e-12 and torch.equal(bn.running_mean, torch.zeros(5))
-    assert float(net[4].bias.abs().sum()) == 0.0           # conv with a bias absorbs the shift
+    assert float(net[4].bias.detach().abs().sum()) == 0.0           # conv with a bias absorbs the shift
 
 
 def test_eval_sparsity_and_accuracy():
