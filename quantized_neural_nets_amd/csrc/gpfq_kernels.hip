@@ -722,7 +722,8 @@ int slab_max_waves(bool coop, int RT);
 // wave that owns its SIMD slot, and the per-CU column traffic / issue contention that grows with the waves on a CU.
 double slab_step_cost(int RT, int waves, int C)
 {
-    return 0.5 + 0.285 * RT + 0.134 * waves + (C >= 16 ? 0.9 : 0.0);
+    // gathering from 16 / 32 / 64 members costs 0.9 / 2.3 / 4 us more than from <= 8 (measured 0.9 and 2.3)
+    return 0.5 + 0.285 * RT + 0.134 * waves + (C >= 64 ? 4.0 : C >= 32 ? 2.3 : C >= 16 ? 0.9 : 0.0);
 }
 
 // Cooperative configuration: cheapest modelled step among the (RT, C) pairs whose grid is co-resident.

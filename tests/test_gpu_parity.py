@@ -188,6 +188,32 @@ def test_cooperative_streaming_configurations(qnn, oracle_mod, monkeypatch, rt, 
     assert np.array_equal(r["U"].cpu().numpy(), o["U"])
 
 
+@pytest.mark.parametrize("N,expect", [(8, "coop RT=1 C=8"), (16, "coop RT="), (32, "coop RT=")])
+def test_eight_gpu_shard_shapes_of_long_rows(qnn, oracle_mod, N, expect):
+    """What one rank of an 8-GPU neuron shard sees for ResNet-50 layer1 / layer2.0 at batch 1024 (m = 93 184, a
+    few rows), bit-exact against the oracle; plus the widest configuration (32 members per row tile), forced."""
+    from quantized_neural_nets_amd import _lib
+    d, m = 18, 93184
+    case = dict(name="shard8", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,
+                first_layer=False, zero_every=7, seed=6)
+    W, A, X = gi.make_inputs(case)
+    assert _lib.describe_plan(N, d, m).startswith(expect), _lib.describe_plan(N, d, m)
+    r = _run_layer(qnn, case, W, A, X, 0)
+    _lib.check_status(DEV)
+    o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, None, 0.0, 1)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+    if N == 8:
+        os.environ["GPFQ_COOP_RT"], os.environ["GPFQ_COOP_C"] = "1", "32"
+        try:
+            assert _lib.describe_plan(N, d, m).startswith("coop RT=1 C=32")
+            r2 = _run_layer(qnn, case, W, A, X, 0)
+            _lib.check_status(DEV)
+        finally:
+            del os.environ["GPFQ_COOP_RT"], os.environ["GPFQ_COOP_C"]
+        assert torch.equal(r2["idx"], r["idx"]) and torch.equal(r2["U"], r["U"])
+
+
 def test_long_layer_crosses_history_blocks(qnn, oracle_mod):
     """d > 64 with d % 64 != 0: the Q / idx history is flushed every 64 columns and once more at the end."""
     case = dict(name="hist", N=6, d=201, m=1500, bits=3, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,

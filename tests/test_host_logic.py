@@ -67,7 +67,7 @@ def test_plan_selection(lib):
     assert lib.describe_plan(128, 1152, 93184).startswith("coop RT=4 C=8 waves=12")
     assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=2 C=4 waves=7")
     assert lib.describe_plan(256, 2304, 26624).startswith("coop RT=4 C=4 waves=7")
-    assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=32 waves=3")        # an 8-GPU shard of 64 rows
+    assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=8 waves=12")        # an 8-GPU shard of 64 rows
     assert lib.describe_plan(64, 9, 30000, 64).startswith("stream")                     # grouped: never cooperative
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
     with pytest.raises(lib.GpfqError):
