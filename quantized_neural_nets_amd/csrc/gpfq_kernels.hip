@@ -377,6 +377,118 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
 // Streaming plan: any (N, m).  The residual rows stay in the caller's U (HBM / L2 / Infinity Cache) and
 // are read and written once per step; wave w owns segments w, w+NW, ... of the workgroup's RT rows.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// One-segment rows (m <= 1024: every fully connected layer, 1x1 convs on 1x1 maps, small depthwise maps):
+// the whole row lives in ONE wave, so the step needs no LDS and no barrier at all -- sweep, lane tree,
+// v_readlane, quantize, next step.  A workgroup is just four independent waves; Q / idx are kept 64 steps in
+// registers (lane l holds step t0 + l) and leave as one coalesced store per row.
+// ------------------------------------------------------------------------------------------------
+template <int RT, int MODE>
+__global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.y;
+    const int row0 = (blockIdx.x * 4 + wave) * RT;  // first row of this wave's tile, inside the group
+    if (row0 >= p.Ng) return;                       // whole wave leaves: nothing is shared between waves
+    const int64_t grow0 = (int64_t)g * p.Ng + row0;
+    const int64_t kbase = 4 * lane;
+    const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+
+    float u[RT][16], xc[16], xo[16], aa[16];
+    const float* __restrict__ wrow[RT];
+    float qprev[RT], wcur[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        wrow[r] = p.W + (grow0 + ((row0 + r < p.Ng) ? r : 0)) * p.ldw;   // rows past the end duplicate the first
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
+        qprev[r] = 0.0f;
+        wcur[r] = wrow[r][0];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xo[e] = 0.0f;
+    load16(xc, xcol);
+    load16(aa, acol);
+    float n2cur = nrm[0];
+    float qh = 0.0f;                                // Q / idx history: lane = (step % 64) * ... one register per row
+    float qhist[RT];
+    int ihist[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) { qhist[r] = 0.0f; ihist[r] = 0; }
+    (void)qh;
+    for (int t = 0; t < p.d; ++t) {
+        const bool more = t + 1 < p.d;
+        float acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r]);
+        // next column: issued right behind the sweep (its latency hides under the reduction and the quantizer);
+        // the opaque asm keeps it from being hoisted above the sweep, unconditional so that no join copy is needed
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xo[e] = xc[e];
+        int64_t adv = more ? p.m_pad : 0;
+        asm volatile("" : "+s"(adv) : "v"(acc[0]));
+        xcol += adv;
+        acol += adv;
+        load16(xc, xcol);
+        load16(aa, acol);
+        float wn[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = more ? wrow[r][t + 1] : 0.0f;
+        const float n2n = more ? nrm[t + 1] : 0.0f;
+        // the RT row totals, row r parked in lane r, then ONE quantizer evaluation for all rows
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float sg = wave_tree64_lane63(acc[r]);
+            const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg), 63));
+            if (lane == r) v = tot;
+        }
+        const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+        int id;
+        const float q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)(grow0 + (lane < RT ? lane : 0)), (uint64_t)t, id);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), r));
+            const int idr = __builtin_amdgcn_readlane(id, r);
+            if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+        }
+        if ((t & 63) == 63 || !more) {
+            const int t0 = t & ~63;
+            if (lane <= t - t0) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (row0 + r < p.Ng) {
+                        const int64_t gw = grow0 + r;
+                        p.Q[gw * p.ldq + t0 + lane] = qhist[r];
+                        if (p.idx) {
+                            if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)ihist[r];
+                            else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)ihist[r];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+        n2cur = n2n;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pq = qprev[r] * xo[e];       // xo = x_{d-1} after the last rotation
+            u[r][e] = u[r][e] - pq;
+        }
+        if (row0 + r < p.Ng) {
+            float* Urow = p.U + (grow0 + r) * p.ldu;
+            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
+            else store_u16<false>(u[r], Urow, kbase, p.m);
+        }
+    }
+}
+
 struct StreamCoop {
     int C;                              // members per row tile (1 = every workgroup owns whole rows)
     int tiles;                          // row tiles
@@ -949,6 +1061,32 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
 {
     const gpfq::SlabParams sp = make_slab_params(pl, p, vec, scratch);
     const int m = p.qc.mode;
+    if (pl.kind == GPFQ_PLAN_RESIDENT && pl.S == 1 && !env_int("GPFQ_NO_WAVE_KERNEL", 0)) {
+        // one wave per row tile; four rows per wave once there are more rows than the chip has wave slots for
+        // (the quantizer then runs once per four rows: the step is VALU-issue-bound at 16 waves per CU)
+        const int wrt = env_int("GPFQ_WAVE_RT", sp.Ng >= 4096 ? 4 : 1) == 4 ? 4 : 1;     // measured: 4096 rows 1.5x faster, 2048 rows 1.3x slower
+        dim3 grid((unsigned)((sp.Ng + 4 * wrt - 1) / (4 * wrt)), (unsigned)groups, 1);
+#define GPFQ_LAUNCH_WAVE(RTV, MODEV) hipLaunchKernelGGL((gpfq::gpfq_wave_kernel<RTV, MODEV>), grid, dim3(256), 0, st, sp)
+        if (wrt == 4) {
+            switch (m) {
+            case gpfq::MODE_SOFT: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_SOFT); break;
+            case gpfq::MODE_HARD: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_HARD); break;
+            case gpfq::MODE_STOCHASTIC: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_STOCHASTIC); break;
+            default: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_MSQ); break;
+            }
+        } else {
+            switch (m) {
+            case gpfq::MODE_SOFT: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_SOFT); break;
+            case gpfq::MODE_HARD: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_HARD); break;
+            case gpfq::MODE_STOCHASTIC: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_STOCHASTIC); break;
+            default: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_MSQ); break;
+            }
+        }
+#undef GPFQ_LAUNCH_WAVE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "GPFQ wave kernel launch");
+        return GPFQ_OK;
+    }
     if (pl.kind == GPFQ_PLAN_RESIDENT) {
         if (pl.RT == 1) return launch_slab_m<1, false, 16>(pl, sp, m, groups, scratch, st);
         if (pl.RT == 2) return launch_slab_m<2, false, 8>(pl, sp, m, groups, scratch, st);

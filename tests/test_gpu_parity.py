@@ -214,6 +214,22 @@ def test_eight_gpu_shard_shapes_of_long_rows(qnn, oracle_mod, N, expect):
         assert torch.equal(r2["idx"], r["idx"]) and torch.equal(r2["U"], r["U"])
 
 
+@pytest.mark.parametrize("wrt", [1, 4])
+def test_one_segment_rows_wave_kernel(qnn, oracle_mod, monkeypatch, wrt):
+    """m <= 1024 (fully connected layers): one wave per row tile, 1 or 4 rows per wave, ragged last tile, history
+    flush across 64-step blocks, grouped."""
+    for (N, d, m, groups, reg) in [(13, 150, 700, 1, None), (9, 70, 1024, 3, "L0")]:
+        case = dict(name="wave", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg=reg, lamb=0.02, groups=groups,
+                    first_layer=False, zero_every=9, seed=12)
+        W, A, X = gi.make_inputs(case)
+        monkeypatch.setenv("GPFQ_WAVE_RT", str(wrt))
+        r = _run_layer(qnn, case, W, A, X, 0)
+        o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, reg, 0.02, groups)
+        assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+        assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
+        assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+
+
 def test_long_layer_crosses_history_blocks(qnn, oracle_mod):
     """d > 64 with d % 64 != 0: the Q / idx history is flushed every 64 columns and once more at the end."""
     case = dict(name="hist", N=6, d=201, m=1500, bits=3, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,

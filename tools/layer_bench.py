@@ -29,7 +29,7 @@ def main():
             kv = dict(x.split("=") for x in cfg.split(","))
             plan = int(kv.pop("plan", "0"))
             for k in list(os.environ):
-                if k.startswith("GPFQ_COOP_"):
+                if k.startswith("GPFQ_") and k != "GPFQ_LIB_OVERRIDE":
                     del os.environ[k]
             os.environ.update(kv)
             StepAlgorithm.plan = plan
