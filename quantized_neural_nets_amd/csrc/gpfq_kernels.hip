@@ -564,26 +564,29 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCo
                 load16(xc, XTg + t * p.m_pad + (int64_t)s * kSeg);
                 load16(ac, ATg + t * p.m_pad + (int64_t)s * kSeg);
             }
+            // all RT residual rows are requested before any of them is used: one round trip per segment, not RT
+            float u[RT][16];
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                float u[16];
-                float* Urow = p.U + grow[r] * p.ldu;
                 if (first && !p.u_has_init) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) u[e] = 0.0f;
+                    for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
                 } else {
-                    load_u16<VEC>(u, Urow, kbase, p.m);
+                    load_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
                 }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
                 if (last) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) { float pq = qprev[r] * xp[e]; u[e] = u[e] - pq; }
+                    for (int e = 0; e < 16; ++e) { float pq = qprev[r] * xp[e]; u[r][e] = u[r][e] - pq; }
                 } else {
-                    float acc = first ? sweep16<false>(u, xc, ac, xc, 0.0f, w[r])
-                                      : sweep16<true>(u, xp, ac, xc, qprev[r], w[r]);
+                    float acc = first ? sweep16<false>(u[r], xc, ac, xc, 0.0f, w[r])
+                                      : sweep16<true>(u[r], xp, ac, xc, qprev[r], w[r]);
                     float sg = wave_tree64_lane63(acc);
                     if (lane == 63) seg[r * n_max + (s - seg_lo)] = sg;
                 }
-                if (valid[r] || RT == 1) store_u16<VEC>(u, Urow, kbase, p.m);
+                if (valid[r] || RT == 1) store_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
             }
         }
         if (last) break;
@@ -887,25 +890,26 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
     pl->waves = S < 8 ? S : 8;
     if (!allow_coop || groups != 1 || env_int("GPFQ_COOP_DISABLE", 0)) return;
     const int force_c = env_int("GPFQ_STREAM_C", 0), force_rt = env_int("GPFQ_STREAM_RT", 0);
-    // Measured (tools/layer_bench.py, N = 64..512, m = 51 200..803 840): once 256 workgroups stream, 1, 2 or 4 rows per
-    // workgroup run within 5 % of each other, and whole rows beat the split whenever they already fill the chip.
-    // So: split only if whole-row workgroups cannot cover the CUs; then two rows per workgroup, most workgroups.
+    // Measured (tools/layer_bench.py, N = 64..512, m = 201 728..803 840): with all RT residual rows requested up
+    // front, four rows per workgroup and enough members to keep one workgroup per CU beat whole rows (N = 256,
+    // m = 803 840: 398 -> 339 us per column; N = 512, m = 201 728: 195 -> 170): fewer column bytes per U byte.
+    // So: most workgroups first (up to one per CU), then most rows per workgroup.
+    // Exception: a residual that fits the 256-MB Infinity Cache with whole rows already covering the chip streams
+    // faster as it is (N = 256, m = 51 200: 15.5 vs 19.1 us).
     int best_rt = pl->RT, best_c = 1;
-    int best_score = (pl->tiles >= cus ? cus : pl->tiles) * 8;
-    if (pl->tiles < cus || (force_c && force_rt)) {
-        const int order[3] = {2, 1, 4};
-        for (int k = 0; k < 3; ++k) {
-            const int RT = order[k];
-            if (force_rt && RT != force_rt) continue;
-            const int64_t tiles = (Ng + RT - 1) / RT;
-            if (tiles > cus) continue;
-            for (int C = 64 / RT; C >= 2; C >>= 1) {
-                if (force_c && C != force_c) continue;
-                if (tiles * C > cus || S / C < 8) continue;       // every member keeps >= 8 segments (one per wave)
-                const int score = (int)tiles * C * 8 + (3 - k);
-                if (score > best_score || (force_c && force_rt)) { best_score = score; best_rt = RT; best_c = C; }
-                break;                                             // largest C for this RT
-            }
+    int best_score = (pl->tiles >= cus ? cus : pl->tiles) * 8 + pl->RT;
+    const bool cache_resident = (double)Ng * S * 4096.0 <= 200e6;
+    if (cache_resident && pl->tiles >= cus && !(force_c && force_rt)) return;
+    for (int RT = 4; RT >= 1; RT >>= 1) {
+        if (force_rt && RT != force_rt) continue;
+        const int64_t tiles = (Ng + RT - 1) / RT;
+        if (tiles > cus) continue;
+        for (int C = 64 / RT; C >= 2; C >>= 1) {
+            if (force_c && C != force_c) continue;
+            if (tiles * C > cus || S / C < 8) continue;           // every member keeps >= 8 segments (one per wave)
+            const int score = (int)tiles * C * 8 + RT;
+            if (score > best_score || (force_c && force_rt)) { best_score = score; best_rt = RT; best_c = C; }
+            break;                                                 // largest C for this RT
         }
     }
     if (best_c > 1) {
