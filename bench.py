@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 stream, 2 resident (debug)")
     ap.add_argument("--layers", default=None, help="substring filter on layer names (debug)")
+    ap.add_argument("--workload", default="r50_3x3", choices=["r50_3x3", "r50_all_convs"],
+                    help="r50_3x3 = the headline config (sixteen 3x3 convs); r50_all_convs = all 53 conv layers (secondary)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -140,7 +142,7 @@ def main():
         qdist.enable()
     StepAlgorithm.plan = args.plan
 
-    layers = bw.resnet50_3x3_layers(args.batch)
+    layers = bw.resnet50_3x3_layers(args.batch) if args.workload == "r50_3x3" else bw.resnet50_all_convs(args.batch)
     if args.layers:
         layers = [l for l in layers if args.layers in l[0]]
     total_weights = sum(N * d for _, N, d, _ in layers)
@@ -256,7 +258,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "ResNet-50 sixteen 3x3 conv2 layers, calibration batch %d, 4-bit (K=8), scalar 1.16, "
+            "config": {"workload": ("ResNet-50 sixteen 3x3 conv2 layers" if args.workload == "r50_3x3" else
+                                    "ResNet-50 all 53 conv layers") + ", calibration batch %d, 4-bit (K=8), scalar 1.16, "
                                    "retain_rate 0.25" % args.batch,
                        "layers": len(layers), "weights": total_weights,
                        "algorithmic_bytes": sum(alg_bytes.values()),
@@ -264,7 +267,7 @@ def main():
             "roofline_whole_job_frac": round(sum(alg_bytes.values()) * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS / max(world, 1), 4),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "r50_3x3":
             out["cpu_baseline"] = cpu_baseline(layers)
         print(json.dumps(out), flush=True)
     if world > 1:

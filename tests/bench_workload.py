@@ -22,6 +22,25 @@ def resnet50_3x3_layers(B=1024):
     return layers
 
 
+def resnet50_all_convs(B=1024):
+    """[(name, N, d, m)] for all 53 conv layers of ResNet-50 in extract_layers order (conv1, conv2, conv3,
+    downsample per Bottleneck; torchvision v1.5: the stride sits on conv2).  m follows the capture rule: the unfold
+    stride is the kernel size, so a 1x1 conv sees every position of its INPUT map whatever its own stride is."""
+    layers = [("conv1", 64, 3 * 49, conv_m(B, 224, 7, 3))]
+    inplanes, H = 64, 56
+    for name, planes, blocks, stride in (("layer1", 64, 3, 1), ("layer2", 128, 4, 2), ("layer3", 256, 6, 2), ("layer4", 512, 3, 2)):
+        for b in range(blocks):
+            s = stride if b == 0 else 1
+            Hout = H // s
+            layers.append(("%s.%d.conv1" % (name, b), planes, inplanes, conv_m(B, H, 1, 0)))
+            layers.append(("%s.%d.conv2" % (name, b), planes, planes * 9, conv_m(B, H, 3, 1)))
+            layers.append(("%s.%d.conv3" % (name, b), planes * 4, planes, conv_m(B, Hout, 1, 0)))
+            if b == 0:
+                layers.append(("%s.0.downsample.0" % name, planes * 4, inplanes, conv_m(B, H, 1, 0)))
+            inplanes, H = planes * 4, Hout
+    return layers
+
+
 def algorithmic_bytes(N, d, m, groups=1):
     """per greedy step of one group 8*N_g*m + 8*m + 8*N_g bytes; per layer groups*d_g times that."""
     Ng = N // groups
