@@ -1,0 +1,624 @@
+// gpfq_capi.hip -- host side of the MI355X GPFQ hot path: plan selection, launches and the C ABI of include/gpfq.h.
+//
+// Path (reference = YixuanSeanZhou/Quantized_Neural_Nets, src/):
+//   StepAlgorithm._quantization   step_algorithm.py:107-148   -> gpfq_loop_kernels.h (slab / wave / stream kernels)
+//   quantizers                    step_algorithm.py:7-104     -> gpfq_device.h quant_*
+//   column reads [:, t], norm     step_algorithm.py:141-144   -> gpfq_prep_kernels.h
+//   conv activation capture       quantize_neural_net.py:334-347 -> gpfq_prep_kernels.h gpfq_gather_patches_kernel
+// Compile with -ffp-contract=off (see gpfq_device.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/gpfq.h"
+#include "gpfq_device.h"
+#include "gpfq_loop_kernels.h"
+#include "gpfq_prep_kernels.h"
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    return fail(GPFQ_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+constexpr int kMaxResidentSegments = 16;
+constexpr size_t kScratchBytes = 128 * 1024;        // [0, 96 KiB) exchange granules, [96 KiB, ...) status words
+constexpr size_t kScratchStatusOffset = 96 * 1024;
+
+struct Plan {
+    int kind;      // GPFQ_PLAN_STREAM / GPFQ_PLAN_RESIDENT / GPFQ_PLAN_COOP
+    int RT;        // rows per workgroup
+    int waves;     // waves per workgroup
+    int S;         // segments per row
+    int C;         // coop: members per row tile
+    int tiles;     // coop: row tiles
+};
+
+int device_cu_count()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+int slab_max_waves(bool coop, int RT);
+
+// Cost model of one column step (microseconds), fitted to MI355X measurements (tools/layer_bench.py): a fixed
+// latency (barriers, reductions, quantizer; plus the granule exchange when cooperative), RT sweeps issued by a
+// wave that owns its SIMD slot, and the per-CU column traffic / issue contention that grows with the waves on a CU.
+double slab_step_cost(int RT, int waves, int C)
+{
+    // gathering from 16 / 32 / 64 members costs 0.9 / 2.3 / 4 us more than from <= 8 (measured 0.9 and 2.3)
+    return 0.5 + 0.285 * RT + 0.134 * waves + (C >= 64 ? 4.0 : C >= 32 ? 2.3 : C >= 16 ? 0.9 : 0.0);
+}
+
+// Cooperative configuration: cheapest modelled step among the (RT, C) pairs whose grid is co-resident.
+// Depends on (Ng, S, CU count) only -- never on the data.
+bool choose_coop(int64_t Ng, int S, int cus, Plan* pl)
+{
+    const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
+    const int wgs_per_cu = env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1;
+    const int capacity = cus * wgs_per_cu;
+    double best = 1e30;
+    bool found = false;
+    for (int RT = 4; RT >= 1; RT >>= 1) {
+        if (force_rt && RT != force_rt) continue;
+        const int64_t tiles = (Ng + RT - 1) / RT;
+        if (tiles > capacity) continue;
+        for (int C = 64 / RT; C >= 2; C >>= 1) {
+            if (force_c && C != force_c) continue;
+            if (C > S || tiles * C > capacity) continue;
+            const int NW = (S + C - 1) / C;
+            if (NW > slab_max_waves(true, RT)) continue;
+            const int wgs = (int)tiles * C;
+            const int per_cu = (wgs + cus - 1) / cus;
+            if ((per_cu * NW + 3) / 4 > 4) continue;
+            // rounds of work if the grid does not cover the chip are not modelled: fewer workgroups than CUs
+            // simply leave CUs idle, which costs nothing per step
+            double cost = slab_step_cost(RT, per_cu * NW, C);
+            if (RT == 4 && NW > 8) cost += 1.2;      // the 12-wave RT=4 variant spills registers
+            if (!found || cost < best - 1e-9) {
+                found = true;
+                best = cost;
+                pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
+            }
+        }
+    }
+    return found;
+}
+
+// Streaming configuration.  Whole rows per workgroup when there are enough rows to fill the chip; otherwise
+// (groups == 1, scratch available) the rows' columns are split over C workgroups so that tiles*C covers the CUs
+// and RT rows share every column load.  Depends on (Ng, S, groups, CU count) only.
+void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
+{
+    const int cus = device_cu_count();
+    pl->kind = GPFQ_PLAN_STREAM;
+    pl->S = S;
+    pl->C = 1;
+    pl->RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
+    pl->tiles = (int)((Ng + pl->RT - 1) / pl->RT);
+    pl->waves = S < 8 ? S : 8;
+    if (!allow_coop || groups != 1 || env_int("GPFQ_COOP_DISABLE", 0)) return;
+    const int force_c = env_int("GPFQ_STREAM_C", 0), force_rt = env_int("GPFQ_STREAM_RT", 0);
+    // Measured (tools/layer_bench.py, N = 64..512, m = 201 728..803 840): with all RT residual rows requested up
+    // front, four rows per workgroup and enough members to keep one workgroup per CU beat whole rows (N = 256,
+    // m = 803 840: 398 -> 339 us per column; N = 512, m = 201 728: 195 -> 170): fewer column bytes per U byte.
+    // So: most workgroups first (up to one per CU), then most rows per workgroup.
+    // Exception: a residual that fits the 256-MB Infinity Cache with whole rows already covering the chip streams
+    // faster as it is (N = 256, m = 51 200: 15.5 vs 19.1 us).
+    int best_rt = pl->RT, best_c = 1;
+    int best_score = (pl->tiles >= cus ? cus : pl->tiles) * 8 + pl->RT;
+    const bool cache_resident = (double)Ng * S * 4096.0 <= 200e6;
+    if (cache_resident && pl->tiles >= cus && !(force_c && force_rt)) return;
+    for (int RT = 4; RT >= 1; RT >>= 1) {
+        if (force_rt && RT != force_rt) continue;
+        const int64_t tiles = (Ng + RT - 1) / RT;
+        if (tiles > cus) continue;
+        for (int C = 64 / RT; C >= 2; C >>= 1) {
+            if (force_c && C != force_c) continue;
+            if (tiles * C > cus || S / C < 8) continue;           // every member keeps >= 8 segments (one per wave)
+            const int score = (int)tiles * C * 8 + RT;
+            if (score > best_score || (force_c && force_rt)) { best_score = score; best_rt = RT; best_c = C; }
+            break;                                                 // largest C for this RT
+        }
+    }
+    if (best_c > 1) {
+        pl->RT = best_rt; pl->C = best_c;
+        pl->tiles = (int)((Ng + best_rt - 1) / best_rt);
+        pl->waves = 8;
+    }
+}
+
+int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, Plan* out)
+{
+    Plan pl;
+    pl.C = 1; pl.tiles = 0;
+    if (m_pad / gpfq::kSeg > 1024) return fail(GPFQ_ERR_UNSUPPORTED, "m > 1048576 calibration rows is not supported");
+    pl.S = (int)(m_pad / gpfq::kSeg);
+    if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_COOP) return fail(GPFQ_ERR_ARG, "unknown plan id");
+    if (requested == GPFQ_PLAN_RESIDENT && pl.S > kMaxResidentSegments)
+        return fail(GPFQ_ERR_UNSUPPORTED, "resident plan needs m_pad <= 16384");
+    const int cus = device_cu_count();
+    if (requested == GPFQ_PLAN_RESIDENT || (requested == GPFQ_PLAN_AUTO && pl.S <= kMaxResidentSegments)) {
+        pl.kind = GPFQ_PLAN_RESIDENT;
+        pl.waves = pl.S;
+        // rows per workgroup: share the activation registers between rows once there are more rows than the
+        // chip has room for one-row workgroups (the roomier variants exist for <= 8 waves)
+        pl.RT = 1;
+        const int force_rt = env_int("GPFQ_RESIDENT_RT", 0);
+        if (pl.S <= 8) {
+            // measured (tools/layer_bench.py): one row per workgroup is never slower than two or four on the
+            // ResNet-50 shapes; the larger variants exist for experiments (GPFQ_RESIDENT_RT)
+            if (force_rt == 1 || force_rt == 2 || force_rt == 4) pl.RT = force_rt;
+        }
+        *out = pl;
+        return GPFQ_OK;
+    }
+    if (requested == GPFQ_PLAN_COOP || (requested == GPFQ_PLAN_AUTO && !env_int("GPFQ_COOP_DISABLE", 0))) {
+        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, &pl)) {
+            *out = pl;
+            return GPFQ_OK;
+        }
+        if (requested == GPFQ_PLAN_COOP)
+            return fail(GPFQ_ERR_UNSUPPORTED, "cooperative plan needs groups == 1, a scratch buffer and a shape that fits");
+    }
+    choose_stream(Ng, pl.S, groups, have_scratch, &pl);
+    *out = pl;
+    return GPFQ_OK;
+}
+
+template <int RT>
+int launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, void* scratch, hipStream_t st)
+{
+    const int S = p.S;
+    const int C = pl.C > 1 ? pl.C : 1;
+    const int n_max = (S + C - 1) / C;
+    dim3 block((unsigned)(64 * pl.waves), 1, 1);
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)n_max + 2 * (RT + 1));
+    gpfq::StreamCoop sc;
+    sc.C = C; sc.tiles = pl.tiles; sc.xbuf = nullptr; sc.status = nullptr;
+    sc.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
+    hipError_t e;
+    if (C > 1) {
+        const int nblocks = pl.tiles * C;
+        int nb = 0;
+        e = vec ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_stream_kernel<RT, true, true>, 64 * pl.waves, shm)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_stream_kernel<RT, false, true>, 64 * pl.waves, shm);
+        if (e != hipSuccess) return hip_fail(e, "occupancy query");
+        const int cus = device_cu_count();
+        if (nb < 1 || (nblocks + cus - 1) / cus > nb) return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
+        size_t xbytes = (size_t)pl.tiles * 2 * C * RT * sizeof(unsigned long long);
+        xbytes = (xbytes + 15) & ~(size_t)15;
+        if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
+        e = hipMemsetAsync(scratch, 0, xbytes, st);
+        if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
+        sc.xbuf = reinterpret_cast<unsigned long long*>(scratch);
+        sc.status = reinterpret_cast<int*>(static_cast<char*>(scratch) + kScratchStatusOffset);
+        dim3 grid((unsigned)nblocks, 1, 1);
+        if (vec) hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, true, true>), grid, block, shm, st, p, sc);
+        else hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, false, true>), grid, block, shm, st, p, sc);
+    } else {
+        dim3 grid((unsigned)((p.Ng + RT - 1) / RT), (unsigned)groups, 1);
+        if (vec) hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, true, false>), grid, block, shm, st, p, sc);
+        else hipLaunchKernelGGL((gpfq::gpfq_stream_kernel<RT, false, false>), grid, block, shm, st, p, sc);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "GPFQ streaming kernel launch");
+    return GPFQ_OK;
+}
+
+gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, bool vec, void* scratch)
+{
+    gpfq::SlabParams sp;
+    sp.W = p.W; sp.Q = p.Q; sp.U = p.U; sp.idx = p.idx; sp.AT = p.AT; sp.XT = p.XT; sp.nrm2 = p.nrm2;
+    sp.xbuf = reinterpret_cast<unsigned long long*>(scratch);
+    sp.status = scratch ? reinterpret_cast<int*>(static_cast<char*>(scratch) + kScratchStatusOffset) : nullptr;
+    sp.ldw = p.ldw; sp.ldq = p.ldq; sp.ldu = p.ldu; sp.ldi = p.ldi; sp.m = p.m; sp.m_pad = p.m_pad;
+    sp.Ng = (int)p.Ng; sp.d = (int)p.d; sp.S = pl.S; sp.C = pl.C; sp.tiles = pl.tiles; sp.idx_bytes = p.idx_bytes;
+    sp.vec = vec ? 1 : 0;
+    sp.step = p.qc.step; sp.Kf = p.qc.Kf; sp.lamb = p.qc.lamb;
+    sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
+    sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
+    return sp;
+}
+
+template <int RT, int MODE, bool COOP, int MAXW>
+int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* scratch, hipStream_t st)
+{
+    if (pl.waves > MAXW) return fail(GPFQ_ERR_UNSUPPORTED, "internal: waves exceed the kernel variant's bound");
+    // one more wave for the reducer role when the variant's register budget allows it
+    const int nwaves = pl.waves + ((pl.waves + 1 <= MAXW && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
+    const int threads = 64 * nwaves;
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1) + 2 * RT * 64);
+    hipError_t e;
+    dim3 grid;
+    if (COOP) {
+        const int nblocks = pl.tiles * pl.C;
+        // every workgroup must be resident at once: check the grid against the occupancy query (the query is
+        // known to over-report by one only near the SGPR limit of >= 6 waves per SIMD; these kernels run at
+        // <= 4, so the answer is taken as is -- and every spin is bounded anyway)
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>, threads, shm);
+        if (e != hipSuccess) return hip_fail(e, "occupancy query");
+        const int cus = device_cu_count();
+        const int need = (nblocks + cus - 1) / cus;
+        if (nb < 1 || need > nb || (need * nwaves + 3) / 4 > 4)
+            return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
+        size_t xbytes = (size_t)pl.tiles * 2 * pl.C * RT * sizeof(unsigned long long);
+        xbytes = (xbytes + 15) & ~(size_t)15;
+        if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
+        e = hipMemsetAsync(scratch, 0, xbytes, st);
+        if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
+        grid = dim3((unsigned)nblocks, 1, 1);
+    } else {
+        grid = dim3((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
+    }
+    hipLaunchKernelGGL((gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>), grid, dim3((unsigned)threads), shm, st, sp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "GPFQ slab kernel launch");
+    return GPFQ_OK;
+}
+
+template <int RT, bool COOP, int MAXW>
+int launch_slab_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, void* scratch, hipStream_t st)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return launch_slab_t<RT, gpfq::MODE_SOFT, COOP, MAXW>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_HARD: return launch_slab_t<RT, gpfq::MODE_HARD, COOP, MAXW>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_STOCHASTIC: return launch_slab_t<RT, gpfq::MODE_STOCHASTIC, COOP, MAXW>(pl, sp, groups, scratch, st);
+    default: return launch_slab_t<RT, gpfq::MODE_MSQ, COOP, MAXW>(pl, sp, groups, scratch, st);
+    }
+}
+
+// The instantiated (rows per workgroup, wave bound) pairs -- keep slab_variant_ok() in step with this switch.
+int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, void* scratch, hipStream_t st)
+{
+    const gpfq::SlabParams sp = make_slab_params(pl, p, vec, scratch);
+    const int m = p.qc.mode;
+    if (pl.kind == GPFQ_PLAN_RESIDENT && pl.S == 1 && !env_int("GPFQ_NO_WAVE_KERNEL", 0)) {
+        // one wave per row tile; four rows per wave once there are more rows than the chip has wave slots for
+        // (the quantizer then runs once per four rows: the step is VALU-issue-bound at 16 waves per CU)
+        const int wrt = env_int("GPFQ_WAVE_RT", sp.Ng >= 4096 ? 4 : 1) == 4 ? 4 : 1;     // measured: 4096 rows 1.5x faster, 2048 rows 1.3x slower
+        dim3 grid((unsigned)((sp.Ng + 4 * wrt - 1) / (4 * wrt)), (unsigned)groups, 1);
+#define GPFQ_LAUNCH_WAVE(RTV, MODEV) hipLaunchKernelGGL((gpfq::gpfq_wave_kernel<RTV, MODEV>), grid, dim3(256), 0, st, sp)
+        if (wrt == 4) {
+            switch (m) {
+            case gpfq::MODE_SOFT: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_SOFT); break;
+            case gpfq::MODE_HARD: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_HARD); break;
+            case gpfq::MODE_STOCHASTIC: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_STOCHASTIC); break;
+            default: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_MSQ); break;
+            }
+        } else {
+            switch (m) {
+            case gpfq::MODE_SOFT: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_SOFT); break;
+            case gpfq::MODE_HARD: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_HARD); break;
+            case gpfq::MODE_STOCHASTIC: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_STOCHASTIC); break;
+            default: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_MSQ); break;
+            }
+        }
+#undef GPFQ_LAUNCH_WAVE
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "GPFQ wave kernel launch");
+        return GPFQ_OK;
+    }
+    if (pl.kind == GPFQ_PLAN_RESIDENT) {
+        if (pl.RT == 1) return launch_slab_m<1, false, 16>(pl, sp, m, groups, scratch, st);
+        if (pl.RT == 2) return launch_slab_m<2, false, 8>(pl, sp, m, groups, scratch, st);
+        return launch_slab_m<4, false, 8>(pl, sp, m, groups, scratch, st);
+    }
+    if (pl.RT == 1) return launch_slab_m<1, true, 12>(pl, sp, m, groups, scratch, st);
+    if (pl.RT == 2) {
+        if (pl.waves <= 8) return launch_slab_m<2, true, 8>(pl, sp, m, groups, scratch, st);
+        return launch_slab_m<2, true, 12>(pl, sp, m, groups, scratch, st);
+    }
+    if (pl.waves <= 8) return launch_slab_m<4, true, 8>(pl, sp, m, groups, scratch, st);
+    return launch_slab_m<4, true, 12>(pl, sp, m, groups, scratch, st);   // 168-VGPR budget: spills a little
+}
+
+// most waves per workgroup an instantiation exists for
+int slab_max_waves(bool coop, int RT)
+{
+    if (!coop) return RT == 1 ? 16 : 8;
+    return 12;
+}
+
+int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scratch_bytes, hipStream_t st)
+{
+    if (p.Ng <= 0 || p.d <= 0 || groups <= 0) return GPFQ_OK;   // nothing to do
+    if (p.Ng > 0x7fffffff || p.d > 0x7fffffff) return fail(GPFQ_ERR_UNSUPPORTED, "N or d beyond 2^31");
+    const bool have_scratch = scratch && scratch_bytes >= kScratchBytes && !(reinterpret_cast<uintptr_t>(scratch) & 255);
+    Plan pl;
+    // the register-resident plans start from U = 0; a caller-provided initial residual (the in-place
+    // _quantization surface) streams through memory
+    if (p.u_has_init && plan == GPFQ_PLAN_AUTO) plan = GPFQ_PLAN_STREAM;
+    if (p.u_has_init && plan != GPFQ_PLAN_STREAM)
+        return fail(GPFQ_ERR_UNSUPPORTED, "an initial residual needs the streaming plan");
+    int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, &pl);
+    if (rc) return rc;
+    if (groups > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "groups > 65535");
+    p.S = pl.S;
+    const bool vec = ((p.ldu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.U) & 15) == 0);
+    if (pl.kind == GPFQ_PLAN_COOP) {
+        rc = launch_slab(pl, p, groups, vec, scratch, st);
+        if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
+        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, &pl);   // does not fit: stream instead
+        if (rc) return rc;
+    }
+    if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_slab(pl, p, groups, vec, scratch, st);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        switch (pl.RT) {
+        case 4: rc = launch_stream<4>(pl, p, groups, vec, scratch, st); break;
+        case 2: rc = launch_stream<2>(pl, p, groups, vec, scratch, st); break;
+        default: rc = launch_stream<1>(pl, p, groups, vec, scratch, st); break;
+        }
+        if (rc != GPFQ_ERR_UNSUPPORTED || pl.C <= 1) return rc;
+        choose_stream(p.Ng, pl.S, groups, false, &pl);          // cooperative grid did not fit: whole rows
+    }
+    return rc;
+}
+
+int check_mode(int mode, int K, int idx_bytes, const void* idx)
+{
+    if (mode < 0 || mode > 3) return fail(GPFQ_ERR_ARG, "mode must be 0..3");
+    if (K < 1) return fail(GPFQ_ERR_ARG, "boundary index K must be >= 1");
+    if (idx) {
+        if (idx_bytes != 1 && idx_bytes != 2) return fail(GPFQ_ERR_ARG, "idx_bytes must be 1 or 2");
+        if (idx_bytes == 1 && K > 126) return fail(GPFQ_ERR_ARG, "int8 indices need K <= 126; use idx_bytes = 2");
+        if (K > 32766) return fail(GPFQ_ERR_ARG, "K too large for int16 indices");
+    }
+    return GPFQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpfq_abi_version(void) { return GPFQ_ABI_VERSION; }
+
+const char* gpfq_last_error(void) { return g_err.c_str(); }
+
+int64_t gpfq_padded_m(int64_t m)
+{
+    if (m < 1) m = 1;
+    return ((m + gpfq::kSeg - 1) / gpfq::kSeg) * gpfq::kSeg;
+}
+
+size_t gpfq_scratch_bytes(void) { return kScratchBytes; }
+
+static size_t ws_cols_bytes(int64_t d_g, int64_t m, int groups)
+{
+    const size_t D = (size_t)d_g * (size_t)groups;
+    return D * (size_t)gpfq_padded_m(m) * sizeof(float);
+}
+static size_t ws_nrm_bytes(int64_t d_g, int groups)
+{
+    return (((size_t)d_g * (size_t)groups * sizeof(float) + 255) / 256) * 256;
+}
+
+size_t gpfq_workspace_bytes(int64_t N, int64_t d_g, int64_t m, int groups)
+{
+    (void)N;
+    if (d_g < 0 || m < 0 || groups < 1) return 0;
+    return kScratchBytes + 2 * ws_cols_bytes(d_g, m, groups) + ws_nrm_bytes(d_g, groups) + 256;
+}
+
+int gpfq_read_status(void* scratch, int* status_host4, void* stream)
+{
+    if (!scratch || !status_host4) return fail(GPFQ_ERR_ARG, "null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    char* sp = static_cast<char*>(scratch) + kScratchStatusOffset;
+    hipError_t e = hipMemcpyAsync(status_host4, sp, 4 * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(e, "status read");
+    if (status_host4[0] != 0) {
+        e = hipMemsetAsync(sp, 0, 4 * sizeof(int), st);
+        if (e != hipSuccess) return hip_fail(e, "status reset");
+        return fail(GPFQ_ERR_TIMEOUT, "cooperative kernel timed out waiting for a peer workgroup");
+    }
+    return GPFQ_OK;
+}
+
+int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
+                             float* AT, float* XT, float* nrm2, int64_t m_pad, void* stream)
+{
+    if (!A || !X || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (m < 0 || D < 0 || lda < D || ldx < D) return fail(GPFQ_ERR_ARG, "bad shape (need lda, ldx >= D)");
+    if (m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "m_pad must equal gpfq_padded_m(m)");
+    if ((reinterpret_cast<uintptr_t>(AT) & 15) || (reinterpret_cast<uintptr_t>(XT) & 15))
+        return fail(GPFQ_ERR_ARG, "AT / XT must be 16-byte aligned");
+    if (D == 0) return GPFQ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(m_pad / 64), (unsigned)((D + 63) / 64), 2);
+    if (grid.y > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "too many columns");
+    hipLaunchKernelGGL(gpfq::gpfq_transpose_pad_kernel, grid, dim3(256), 0, st, A, lda, X, ldx, m, D, AT, XT, m_pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "transpose launch");
+    const int S = (int)(m_pad / gpfq::kSeg);
+    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(256), sizeof(float) * (size_t)S, st, XT, m_pad,
+                       S, nrm2);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "colnorm launch");
+    return GPFQ_OK;
+}
+
+int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, float* U, int64_t ldu,
+                          int u_has_init, const float* AT, const float* XT, const float* nrm2,
+                          int64_t N, int64_t d, int64_t m, int64_t m_pad,
+                          float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
+                          void* idx, int64_t ldi, int idx_bytes, int plan, void* scratch, size_t scratch_bytes,
+                          void* stream)
+{
+    if (!W || !Q || !U || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (N < 0 || d < 0 || m < 0 || ldw < d || ldq < d || ldu < m || (idx && ldi < d))
+        return fail(GPFQ_ERR_ARG, "bad shape / leading dimension");
+    if (m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "m_pad must equal gpfq_padded_m(m)");
+    int rc = check_mode(mode, K, idx_bytes, idx);
+    if (rc) return rc;
+    gpfq::LoopParams p;
+    p.W = W; p.ldw = ldw; p.Q = Q; p.ldq = ldq; p.U = U; p.ldu = ldu; p.u_has_init = u_has_init;
+    p.AT = AT; p.XT = XT; p.nrm2 = nrm2; p.Ng = N; p.d = d; p.m = m; p.m_pad = m_pad; p.S = 0;
+    p.qc.step = step; p.qc.Kf = (float)K; p.qc.lamb = lamb; p.qc.mode = mode; p.qc.seed = seed;
+    p.row_id0 = row_id0; p.idx = idx; p.ldi = ldi; p.idx_bytes = idx_bytes;
+    return run_loop(p, 1, plan, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const float* AT, const float* XT,
+                                      const float* nrm2, int64_t N, int64_t d_g, int64_t m, int64_t m_pad,
+                                      int groups, float step, int K, int mode, float lamb, uint64_t seed,
+                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* scratch,
+                                      size_t scratch_bytes, void* stream)
+{
+    if (!W || !Q || !U || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (groups < 1 || N < 0 || d_g < 0 || m < 0) return fail(GPFQ_ERR_ARG, "bad shape");
+    if (N % groups != 0) return fail(GPFQ_ERR_ARG, "N must be divisible by groups");
+    if (m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "m_pad must equal gpfq_padded_m(m)");
+    int rc = check_mode(mode, K, idx_bytes, idx);
+    if (rc) return rc;
+    gpfq::LoopParams p;
+    p.W = W; p.ldw = d_g; p.Q = Q; p.ldq = d_g; p.U = U; p.ldu = m; p.u_has_init = 0;
+    p.AT = AT; p.XT = XT; p.nrm2 = nrm2; p.Ng = N / groups; p.d = d_g; p.m = m; p.m_pad = m_pad; p.S = 0;
+    p.qc.step = step; p.qc.Kf = (float)K; p.qc.lamb = lamb; p.qc.mode = mode; p.qc.seed = seed;
+    p.row_id0 = row_id0; p.idx = idx; p.ldi = d_g; p.idx_bytes = idx_bytes;
+    return run_loop(p, groups, plan, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const float* X, int64_t ldx,
+                            int64_t N, int64_t d_g, int64_t m, int groups,
+                            float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
+                            float* Q, void* idx, int idx_bytes, float* U,
+                            void* workspace, size_t workspace_bytes, int plan, void* stream)
+{
+    if (!W || !A || !X || !Q || !U || !workspace) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (groups < 1 || N < 0 || d_g < 0 || m < 0) return fail(GPFQ_ERR_ARG, "bad shape");
+    if (N % groups != 0) return fail(GPFQ_ERR_ARG, "N must be divisible by groups");
+    const int64_t D = d_g * (int64_t)groups;
+    if (lda < D || ldx < D) return fail(GPFQ_ERR_ARG, "A / X need groups*d_g columns");
+    int rcm = check_mode(mode, K, idx_bytes, idx);
+    if (rcm) return rcm;
+    if (workspace_bytes < gpfq_workspace_bytes(N, d_g, m, groups))
+        return fail(GPFQ_ERR_WORKSPACE, "workspace smaller than gpfq_workspace_bytes()");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(GPFQ_ERR_ARG, "workspace must be 256-byte aligned");
+    const int64_t mp = gpfq_padded_m(m);
+    char* ws = static_cast<char*>(workspace);          // [scratch][AT][XT][nrm2]
+    const size_t cb = ws_cols_bytes(d_g, m, groups);
+    float* AT = reinterpret_cast<float*>(ws + kScratchBytes);
+    float* XT = reinterpret_cast<float*>(ws + kScratchBytes + cb);
+    float* nrm2 = reinterpret_cast<float*>(ws + kScratchBytes + 2 * cb);
+    int rc = gpfq_prepare_columns_f32(A, lda, X, ldx, m, D, AT, XT, nrm2, mp, stream);
+    if (rc) return rc;
+    return gpfq_quantize_groups_prepared_f32(W, Q, U, AT, XT, nrm2, N, d_g, m, mp, groups, step, K, mode, lamb, seed,
+                                             row_id0, idx, idx_bytes, plan, ws, kScratchBytes, stream);
+}
+
+int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, float lamb,
+                       const float* uniform, float* out, int32_t* idx, void* stream)
+{
+    if (!x || !out) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (mode < 0 || mode > 3 || K < 1 || n < 0) return fail(GPFQ_ERR_ARG, "bad argument");
+    if (n == 0) return GPFQ_OK;
+    hipLaunchKernelGGL(gpfq::gpfq_quantizer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, mode, step, x, n, (float)K, lamb, uniform, out, idx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "quantizer launch");
+    return GPFQ_OK;
+}
+
+int gpfq_column_norms_f32(const float* XT, int64_t D, int64_t m, int64_t m_pad, float* nrm2, void* stream)
+{
+    if (!XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (D < 0 || m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "bad shape (m_pad must equal gpfq_padded_m(m))");
+    if (D == 0) return GPFQ_OK;
+    const int S = (int)(m_pad / gpfq::kSeg);
+    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(256), sizeof(float) * (size_t)S,
+                       (hipStream_t)stream, XT, m_pad, S, nrm2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "colnorm launch");
+    return GPFQ_OK;
+}
+
+int gpfq_gather_patches_f32(const float* x, int64_t B, int64_t C, int64_t H, int64_t W, int kh, int kw, int pad_h,
+                            int pad_w, int dil_h, int dil_w, const int64_t* patch_index, int64_t m, float* outT,
+                            int64_t m_pad, void* stream)
+{
+    if (!x || !outT || (!patch_index && m > 0)) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (B < 1 || C < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || dil_h < 1 || dil_w < 1 || pad_h < 0 || pad_w < 0 || m < 0)
+        return fail(GPFQ_ERR_ARG, "bad shape");
+    if (m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "m_pad must equal gpfq_padded_m(m)");
+    // nn.Unfold(kernel, dilation, padding, stride = kernel): blocks per axis
+    const int64_t Lh = (H + 2 * pad_h - (int64_t)dil_h * (kh - 1) - 1) / kh + 1;
+    const int64_t Lw = (W + 2 * pad_w - (int64_t)dil_w * (kw - 1) - 1) / kw + 1;
+    if (Lh < 1 || Lw < 1) return fail(GPFQ_ERR_ARG, "kernel larger than the padded input");
+    const int64_t D = C * kh * kw;
+    if (D > 0x7fffffff || C * H * W > 0x7fffffffffffLL) return fail(GPFQ_ERR_UNSUPPORTED, "feature map too large");
+    dim3 grid((unsigned)(m_pad / 64), (unsigned)((D + 63) / 64), 1);
+    if (grid.y > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "too many features");
+    hipLaunchKernelGGL(gpfq::gpfq_gather_patches_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (int)C, (int)H, (int)W,
+                       kh, kw, pad_h, pad_w, dil_h, dil_w, (int)Lw, Lh * Lw, patch_index, m, outT, m_pad, (int)D);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "gather_patches launch");
+    (void)B;
+    return GPFQ_OK;
+}
+
+int gpfq_row_absmax_f32(const float* W, int64_t ldw, int64_t N, int64_t d, float* rowmax, void* stream)
+{
+    if (!W || !rowmax) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (N < 0 || d < 0 || ldw < d) return fail(GPFQ_ERR_ARG, "bad shape");
+    if (N == 0) return GPFQ_OK;
+    hipLaunchKernelGGL(gpfq::gpfq_row_absmax_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, W, ldw, d,
+                       rowmax);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "row_absmax launch");
+    return GPFQ_OK;
+}
+
+int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, char* buf, size_t buf_bytes)
+{
+    if (groups < 1 || N % groups != 0) return fail(GPFQ_ERR_ARG, "bad groups");
+    Plan pl;
+    int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, &pl);
+    if (rc) return rc;
+    if (buf && buf_bytes) {
+        if (pl.kind == GPFQ_PLAN_COOP)
+            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
+                     pl.tiles * pl.C, (long long)d_g);
+        else if (pl.kind == GPFQ_PLAN_STREAM && pl.C > 1)
+            snprintf(buf, buf_bytes, "stream RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
+                     pl.tiles * pl.C, (long long)d_g);
+        else
+            snprintf(buf, buf_bytes, "%s RT=%d waves=%d S=%d grid=(%lld,%d) d=%lld",
+                     pl.kind == GPFQ_PLAN_RESIDENT ? "resident" : "stream", pl.RT, pl.waves, pl.S,
+                     (long long)((N / groups + pl.RT - 1) / pl.RT), groups, (long long)d_g);
+    }
+    return pl.kind;
+}
+
+}  // extern "C"

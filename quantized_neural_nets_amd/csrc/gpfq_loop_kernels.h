@@ -1,0 +1,640 @@
+// gpfq_loop_kernels.h -- the GPFQ loop kernels (gfx950): gpfq_slab_kernel (residual resident in registers, whole rows
+// or rows split over co-operating workgroups), gpfq_wave_kernel (one-segment rows, one wave per row tile) and
+// gpfq_stream_kernel (residual streamed through HBM / L2).  Reference: StepAlgorithm._quantization,
+// step_algorithm.py:107-148.  One launch runs the WHOLE column loop of a layer (all groups): rows of the residual U
+// are independent, and per step a workgroup makes ONE pass over its rows, fusing
+//   u -= q_{t-1} x_{t-1};  u += w_t a_t;  <u, x_t>.
+#pragma once
+#include "gpfq_device.h"
+
+namespace gpfq {
+
+struct LoopParams {
+    const float* W; int64_t ldw;
+    float* Q; int64_t ldq;
+    float* U; int64_t ldu; int u_has_init;
+    const float* AT; const float* XT; const float* nrm2;
+    int64_t Ng;        // rows per group
+    int64_t d;         // columns per group
+    int64_t m; int64_t m_pad; int S;
+    QuantCfg qc;
+    uint64_t row_id0;
+    void* idx; int64_t ldi; int idx_bytes;
+};
+
+__device__ __forceinline__ void store_q(const LoopParams& p, int64_t grow, int64_t t, float q, int id)
+{
+    p.Q[grow * p.ldq + t] = q;
+    if (p.idx) {
+        if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[grow * p.ldi + t] = (int8_t)id;
+        else reinterpret_cast<int16_t*>(p.idx)[grow * p.ldi + t] = (int16_t)id;
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void load_u16(float (&u)[16], const float* __restrict__ Urow, int64_t kbase, int64_t m)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t k0 = kbase + 256 * c;
+        if (VEC && k0 + 3 < m) {
+            float4 v = *reinterpret_cast<const float4*>(Urow + k0);
+            u[4 * c + 0] = v.x; u[4 * c + 1] = v.y; u[4 * c + 2] = v.z; u[4 * c + 3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[4 * c + j] = (k0 + j < m) ? Urow[k0 + j] : 0.0f;
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void store_u16(const float (&u)[16], float* __restrict__ Urow, int64_t kbase, int64_t m)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t k0 = kbase + 256 * c;
+        if (VEC && k0 + 3 < m) {
+            *reinterpret_cast<float4*>(Urow + k0) = make_float4(u[4 * c + 0], u[4 * c + 1], u[4 * c + 2], u[4 * c + 3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < m) Urow[k0 + j] = u[4 * c + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Slab plans (resident / cooperative): the residual lives in registers for the whole column loop.
+//
+// A workgroup owns an RT x (n_own segments) slab of U: RT rows sharing the activation registers, one wave
+// per canonical segment.  Per step: every wave sweeps its segment (fused update + fma chain, sweep16) and
+// reduces the 64 lane chains (wave_tree64); wave 0 then finishes the canonical slot tree, divides by the
+// column norm, quantizes (the RT rows in RT different lanes) and hands q back through LDS.
+//
+//   resident (COOP = false): one workgroup holds whole rows (S <= 16 segments).  HBM/L2 traffic per step is
+//     only x_{t+1}, a_{t+1}, prefetched behind the reduction of step t.
+//   cooperative (COOP = true): a row is split by columns over C workgroups ("members"), needed when rows are
+//     too long for one workgroup's registers or too few to fill the chip.  Each member reduces its own
+//     aligned block of the slot tree, publishes RT partial sums as 8-byte {value, epoch} granules (one
+//     write-through store each: the data is the flag), gathers the C*RT <= 64 granules of its row tile with
+//     one load per lane per poll, finishes the tree over the C members and quantizes.  Every member computes
+//     the same bits, so nothing else is exchanged.  Placement-independent: correctness needs only that all
+//     workgroups are resident (the host sizes the grid from the occupancy query); spins are bounded and a
+//     timeout raises the status word instead of hanging.
+// ------------------------------------------------------------------------------------------------
+struct SlabParams {
+    const float* W; float* Q; float* U; void* idx;
+    const float* AT; const float* XT; const float* nrm2;
+    unsigned long long* xbuf; int* status;
+    int64_t ldw, ldq, ldu, ldi, m, m_pad;
+    int Ng, d, S, C, tiles, idx_bytes, vec;
+    float step, Kf, lamb;
+    unsigned spin_limit;
+    uint64_t seed, row_id0;
+};
+
+template <int MODE>
+__device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uint64_t row, uint64_t col, int& id)
+{
+    if (MODE == MODE_SOFT) return quant_soft(p.step, s, p.Kf, p.lamb, id);
+    if (MODE == MODE_HARD) return quant_hard(p.step, s, p.Kf, p.lamb, id);
+    if (MODE == MODE_STOCHASTIC) return quant_stochastic(p.step, s, p.Kf, philox_uniform(p.seed, row, col), id);
+    return quant_msq(p.step, s, p.Kf, id);
+}
+
+// The reducer's serial section of one step (one wave, EXEC full): finish this workgroup's block of the slot tree
+// for all RT rows at once (lane = row*nl + slot), exchange with the other members when cooperative, divide by the
+// column norm, quantize the RT rows in RT lanes, hand q back through LDS and write Q / idx.
+template <int RT, int MODE, bool COOP>
+__device__ __forceinline__ void reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
+                                        int NW, int nl, int rlane, int lane, int tile, int c, int C, int par,
+                                        int t, float n2cur, int row0, int64_t grow0, int seg_lo)
+{
+    // this workgroup's block of the slot tree for all RT rows at once: blocks of nl lanes
+    float v;
+    {
+        const int rr = rlane < RT ? rlane : 0;
+        const float val = seg[rr * NW + (smap.s0 - seg_lo)];
+        v = ((smap.mask & 1u) && rlane < RT) ? val : 0.0f;
+        v = wave_tree_n(v, nl);
+    }
+    bool timed_out = false;
+    int blk = nl;                            // lanes r*blk .. r*blk+blk-1 hold row r's value
+    if (COOP) {
+        const unsigned epoch = (unsigned)t + 1u;
+        unsigned long long* xb_ = p.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
+        if ((lane % nl) == 0 && rlane < RT)
+            __hip_atomic_store(xb_ + (size_t)c * RT + rlane,
+                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // gather: lane = r*C + member
+        const bool want = lane < RT * C;
+        const unsigned long long* src = xb_ + (want ? (size_t)(lane % C) * RT + (lane / C) : 0);
+        unsigned long long gv = 0;
+        unsigned spins = 0;
+        for (;;) {
+            gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = !want || ((unsigned)(gv >> 32) == epoch);
+            if (__all(ok)) break;
+            if (++spins > p.spin_limit) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        v = want ? __uint_as_float((unsigned)gv) : 0.0f;
+        v = wave_tree_n(v, C);               // upper levels of the slot tree, per aligned block of C lanes
+        blk = C;
+    }
+    const int gr_ = lane / blk;              // row of this lane
+    const bool lead = (lane % blk == 0) && gr_ < RT;
+    const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+    const bool rvalid = lead && (row0 + gr_ < p.Ng);
+    const int64_t growl = grow0 + (rvalid ? gr_ : 0);
+    int id;
+    const float q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
+    if (lead) qs[par * (RT + 1) + gr_] = q;
+    // Q / idx leave through a 64-step history in LDS and one coalesced store per row every 64 steps: a
+    // store per step would queue behind the sweep waves' column loads in the vector-memory pipe and hold up
+    // the reducer's arrival at the second barrier.
+    float* hist = qs + 2 * (RT + 1);                 // [RT][64] values, then [RT][64] indices (as int bits)
+    if (lead) {
+        hist[gr_ * 64 + (t & 63)] = q;
+        hist[(RT + gr_) * 64 + (t & 63)] = __int_as_float(id);
+    }
+    if ((t & 63) == 63 || t + 1 == p.d) {
+        const int t0 = t & ~63;
+        const int n = t - t0 + 1;                    // steps in this history block
+        if (c == 0 && lane < n) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (row0 + r < p.Ng) {
+                    const int64_t gw = grow0 + r;
+                    p.Q[gw * p.ldq + t0 + lane] = hist[r * 64 + lane];
+                    if (p.idx) {
+                        const int iv = __float_as_int(hist[(RT + r) * 64 + lane]);
+                        if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)iv;
+                        else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)iv;
+                    }
+                }
+            }
+        }
+    }
+    if (COOP && lane == 0) {
+        qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
+        if (timed_out) {
+            atomicExch(p.status, 1);
+            p.status[1] = t; p.status[2] = tile; p.status[3] = c;
+        }
+    }
+}
+
+// MAXW = most waves per workgroup the instantiation may be launched with; it sets the register budget
+// (16 waves -> 128 VGPRs, 12 -> 168, 8 -> 256): more rows per workgroup need the roomier variants.
+template <int RT, int MODE, bool COOP, int MAXW>
+__global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p)
+{
+    extern __shared__ float smem[];                 // seg[2][RT][NW], then qs[2][RT + 1]
+    const int NW = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int S = p.S, C = COOP ? p.C : 1;
+    const int P = pow2_ceil(S);
+    int tile, c, g;
+    if (COOP) {
+        g = 0;
+        // keep the members of one row tile on one XCD when the tile count allows it (blocks b and b+8 share an
+        // XCD under round-robin dispatch; speed only, never correctness)
+        if ((p.tiles & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            tile = (j / C) * 8 + xcd;
+            c = j % C;
+        } else {
+            tile = blockIdx.x / C;
+            c = blockIdx.x % C;
+        }
+    } else {
+        tile = blockIdx.x; c = 0; g = blockIdx.y;
+    }
+    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
+    const int n_own = seg_hi - seg_lo;              // <= max_own
+    const int max_own = (S + C - 1) / C;            // sweep waves of the fullest member
+    // The reducer (slot tree, exchange, quantizer) is a wave of its own when the launch has one to spare
+    // (NW == max_own + 1): its serial section is then not delayed by its own column loads; otherwise wave 0
+    // doubles as the reducer.
+    const int rwave = NW > max_own ? max_own : 0;
+    const bool active = wave < n_own;
+    const int myseg = seg_lo + (active ? wave : 0);
+    const int nl = P / C;                           // slots of this workgroup's block; RT*nl <= 64 (host guarantees it)
+    // wave 0 reduces all RT rows at once: lane = r*nl + slot
+    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane % nl, nl);
+    const int rlane = lane / nl;                    // row whose slot this lane holds (>= RT: idle)
+
+    float* segs = smem;                             // [2][RT][NW]
+    float* qs = smem + 2 * RT * NW;                 // [2][RT + 1] (last = abort flag), then the Q / idx history [2*RT][64]
+
+    const int row0 = tile * RT;                     // row inside the group
+    const int64_t grow0 = (int64_t)g * p.Ng + row0; // global row of this tile's first row
+    const int64_t kbase = (int64_t)myseg * kSeg + 4 * lane;
+    const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+
+    float u[RT][16];
+    const float* __restrict__ wrow[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
+        wrow[r] = p.W + gr * p.ldw;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;   // a non-zero initial residual is the streaming plan's job
+    }
+    float qprev[RT], wcur[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) { qprev[r] = 0.0f; wcur[r] = wrow[r][0]; }
+    float n2cur = nrm[0];
+
+    // xc = x_t, xo = x_{t-1} (all zero at t = 0, where q_{-1} = 0), aa = a_t
+    float xc[16], xo[16], aa[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { xc[e] = 0.0f; xo[e] = 0.0f; aa[e] = 0.0f; }
+    if (active) { load16(xc, xcol); load16(aa, acol); }
+
+#ifdef GPFQ_STAMPS
+    // diagnostic build only: cycles per phase, summed by wave 0 (and the last wave) of block 0 into status[16..]
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_prev = 0;
+#define GPFQ_STAMP(i)                                                                                   \
+    {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long now_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        stamp_sum[i] += now_ - stamp_prev;                                                              \
+        stamp_prev = now_;                                                                              \
+    }
+#else
+#define GPFQ_STAMP(i)
+#endif
+    bool dead = false;
+    int t = 0;
+#ifdef GPFQ_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    while (t < p.d && !dead) {
+        GPFQ_STAMP(0)
+        const int par = t & 1;
+        const bool more = t + 1 < p.d;
+        float* seg = segs + par * RT * NW;
+        float wn[RT], n2n = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = 0.0f;
+        if (active) {
+            float acc[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r]);
+            GPFQ_STAMP(1)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float sg = wave_tree64_lane63(acc[r]);
+                if (lane == 63) seg[r * NW + wave] = sg;
+            }
+            GPFQ_STAMP(2)
+        }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
+            n2n = nrm[t + 1];
+        }
+        __syncthreads();
+        GPFQ_STAMP(3)
+        // Next column's loads, issued OFF the critical path (the sweep waves idle until the reducer is done) and
+        // landing in the registers the sweep just finished with.  The opaque asm keeps LLVM from hoisting them
+        // (they depend on nothing here): hoisted above the sweep they need 32 more VGPRs and a copy that waits
+        // for them before the barrier, and their issue stalls (~60-180 cycles each) sit on the critical path.
+        auto issue_loads = [&]() {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) xo[e] = xc[e];
+            int64_t adv = more ? p.m_pad : 0;        // the last step re-reads its own column: no join copy
+            asm volatile("" : "+s"(adv)::"memory");
+            xcol += adv;
+            acol += adv;
+            load16(xc, xcol);
+            load16(aa, acol);
+        };
+        if (active && wave != rwave) issue_loads();
+        if (wave == rwave) {
+            GPFQ_STAMP(4)
+            reducer_section<RT, MODE, COOP>(p, seg, qs, smap, NW, nl, rlane, lane, tile, c, C, par, t, n2cur, row0, grow0,
+                                            seg_lo);
+            GPFQ_STAMP(5)
+        }
+        if (active && wave == rwave) issue_loads();
+        GPFQ_STAMP(6)
+        __syncthreads();
+        GPFQ_STAMP(7)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
+        if (COOP) dead = qs[par * (RT + 1) + RT] != 0.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+        n2cur = n2n;
+        ++t;
+    }
+#ifdef GPFQ_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == rwave || wave == (rwave == 0 ? NW - 1 : 0)) && p.status) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 16) + (wave == rwave ? 0 : 8);
+        for (int i = 0; i < 8; ++i) dbg[i] = stamp_sum[i];
+    }
+#endif
+    if (dead || !active) return;
+
+    // pending subtraction of the last step, then write the residual (step_algorithm.py:148)
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pq = qprev[r] * xo[e];       // xo = x_{d-1} after the last rotation
+            u[r][e] = u[r][e] - pq;
+        }
+        if (row0 + r < p.Ng) {
+            float* Urow = p.U + (grow0 + r) * p.ldu;
+            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
+            else store_u16<false>(u[r], Urow, kbase, p.m);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Streaming plan: any (N, m).  The residual rows stay in the caller's U (HBM / L2 / Infinity Cache) and
+// are read and written once per step; wave w owns segments w, w+NW, ... of the workgroup's RT rows.
+// ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// One-segment rows (m <= 1024: every fully connected layer, 1x1 convs on 1x1 maps, small depthwise maps):
+// the whole row lives in ONE wave, so the step needs no LDS and no barrier at all -- sweep, lane tree,
+// v_readlane, quantize, next step.  A workgroup is just four independent waves; Q / idx are kept 64 steps in
+// registers (lane l holds step t0 + l) and leave as one coalesced store per row.
+// ------------------------------------------------------------------------------------------------
+template <int RT, int MODE>
+__global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.y;
+    const int row0 = (blockIdx.x * 4 + wave) * RT;  // first row of this wave's tile, inside the group
+    if (row0 >= p.Ng) return;                       // whole wave leaves: nothing is shared between waves
+    const int64_t grow0 = (int64_t)g * p.Ng + row0;
+    const int64_t kbase = 4 * lane;
+    const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
+    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+
+    float u[RT][16], xc[16], xo[16], aa[16];
+    const float* __restrict__ wrow[RT];
+    float qprev[RT], wcur[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        wrow[r] = p.W + (grow0 + ((row0 + r < p.Ng) ? r : 0)) * p.ldw;   // rows past the end duplicate the first
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
+        qprev[r] = 0.0f;
+        wcur[r] = wrow[r][0];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xo[e] = 0.0f;
+    load16(xc, xcol);
+    load16(aa, acol);
+    float n2cur = nrm[0];
+    float qh = 0.0f;                                // Q / idx history: lane = (step % 64) * ... one register per row
+    float qhist[RT];
+    int ihist[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) { qhist[r] = 0.0f; ihist[r] = 0; }
+    (void)qh;
+    for (int t = 0; t < p.d; ++t) {
+        const bool more = t + 1 < p.d;
+        float acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r]);
+        // next column: issued right behind the sweep (its latency hides under the reduction and the quantizer);
+        // the opaque asm keeps it from being hoisted above the sweep, unconditional so that no join copy is needed
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xo[e] = xc[e];
+        int64_t adv = more ? p.m_pad : 0;
+        asm volatile("" : "+s"(adv) : "v"(acc[0]));
+        xcol += adv;
+        acol += adv;
+        load16(xc, xcol);
+        load16(aa, acol);
+        float wn[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = more ? wrow[r][t + 1] : 0.0f;
+        const float n2n = more ? nrm[t + 1] : 0.0f;
+        // the RT row totals, row r parked in lane r, then ONE quantizer evaluation for all rows
+        float v = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float sg = wave_tree64_lane63(acc[r]);
+            const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg), 63));
+            if (lane == r) v = tot;
+        }
+        const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+        int id;
+        const float q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)(grow0 + (lane < RT ? lane : 0)), (uint64_t)t, id);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), r));
+            const int idr = __builtin_amdgcn_readlane(id, r);
+            if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+        }
+        if ((t & 63) == 63 || !more) {
+            const int t0 = t & ~63;
+            if (lane <= t - t0) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (row0 + r < p.Ng) {
+                        const int64_t gw = grow0 + r;
+                        p.Q[gw * p.ldq + t0 + lane] = qhist[r];
+                        if (p.idx) {
+                            if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)ihist[r];
+                            else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)ihist[r];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+        n2cur = n2n;
+    }
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pq = qprev[r] * xo[e];       // xo = x_{d-1} after the last rotation
+            u[r][e] = u[r][e] - pq;
+        }
+        if (row0 + r < p.Ng) {
+            float* Urow = p.U + (grow0 + r) * p.ldu;
+            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
+            else store_u16<false>(u[r], Urow, kbase, p.m);
+        }
+    }
+}
+
+struct StreamCoop {
+    int C;                              // members per row tile (1 = every workgroup owns whole rows)
+    int tiles;                          // row tiles
+    unsigned long long* xbuf;           // exchange granules [tiles][2][C][RT] (C > 1 only)
+    int* status;
+    unsigned spin_limit;
+};
+
+// COOP = false: workgroup (blockIdx.x, blockIdx.y = group) owns RT whole rows.
+// COOP = true : groups == 1; a row tile's columns are split over C workgroups (block -> (tile, member) as in the
+//               slab kernel), each streams its segment range and the per-row partial sums are exchanged per step
+//               with the same granule protocol -- so that few long rows still fill every CU and RT rows share each
+//               column load.
+template <int RT, bool VEC, bool COOP>
+__global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCoop sc)
+{
+    extern __shared__ float smem[];                 // seg[2][RT][n_max] | qs[2][RT+1]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int NW = blockDim.x >> 6;
+    const int S = p.S, C = COOP ? sc.C : 1;
+    const int P = pow2_ceil(S);
+    int tile, c, g;
+    if (COOP) {
+        g = 0;
+        if ((sc.tiles & 7) == 0) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            tile = (j / C) * 8 + xcd;
+            c = j % C;
+        } else {
+            tile = blockIdx.x / C;
+            c = blockIdx.x % C;
+        }
+    } else {
+        tile = blockIdx.x; c = 0; g = blockIdx.y;
+    }
+    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
+    const int n_max = (S + C - 1) / C;              // LDS row length (segments of the fullest member)
+    const int bslots = P / C;                       // this member's aligned block of the slot tree
+    const int per = bslots > 64 ? bslots / 64 : 1, nl = bslots > 64 ? 64 : bslots;
+    const SlotMap smap = make_slot_map(S, P, c * bslots, per, lane, nl);
+    float* segs = smem;
+    float* qs = smem + 2 * RT * n_max;
+
+    const int64_t row0 = (int64_t)tile * RT;
+    const float* __restrict__ ATg = p.AT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
+    const float* __restrict__ XTg = p.XT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
+    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+
+    int64_t grow[RT];
+    bool valid[RT];
+    float qprev[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        valid[r] = (row0 + r) < p.Ng;
+        grow[r] = (int64_t)g * p.Ng + (valid[r] ? row0 + r : p.Ng - 1);
+        qprev[r] = 0.0f;
+    }
+
+    bool dead = false;
+    for (int64_t t = 0; t <= p.d && !dead; ++t) {
+        const bool last = (t == p.d);               // extra pass: only the pending subtraction
+        const bool first = (t == 0);
+        const int par = (int)(t & 1);
+        float w[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) w[r] = last ? 0.0f : p.W[grow[r] * p.ldw + t];
+        float* seg = segs + (size_t)par * RT * n_max;
+        for (int s = seg_lo + wave; s < seg_hi; s += NW) {
+            const int64_t kbase = (int64_t)s * kSeg + 4 * lane;
+            float xp[16], xc[16], ac[16];
+            if (!first) load16(xp, XTg + (t - 1) * p.m_pad + (int64_t)s * kSeg);
+            if (!last) {
+                load16(xc, XTg + t * p.m_pad + (int64_t)s * kSeg);
+                load16(ac, ATg + t * p.m_pad + (int64_t)s * kSeg);
+            }
+            // all RT residual rows are requested before any of them is used: one round trip per segment, not RT
+            float u[RT][16];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (first && !p.u_has_init) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
+                } else {
+                    load_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if (last) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { float pq = qprev[r] * xp[e]; u[r][e] = u[r][e] - pq; }
+                } else {
+                    float acc = first ? sweep16<false>(u[r], xc, ac, xc, 0.0f, w[r])
+                                      : sweep16<true>(u[r], xp, ac, xc, qprev[r], w[r]);
+                    float sg = wave_tree64_lane63(acc);
+                    if (lane == 63) seg[r * n_max + (s - seg_lo)] = sg;
+                }
+                if (valid[r] || RT == 1) store_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
+            }
+        }
+        if (last) break;
+        __syncthreads();
+        if (wave == 0) {
+            // this member's block of the slot tree, row r's value parked in lane r
+            float mine = 0.0f;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const float pr = combine_slots(seg + r * n_max - seg_lo, smap, per, nl, seg_hi - 1);
+                if (lane == r) mine = pr;
+            }
+            float v = mine;
+            int blk = 1;
+            bool timed_out = false;
+            if (COOP) {
+                const unsigned epoch = (unsigned)t + 1u;
+                unsigned long long* xb_ = sc.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
+                if (lane < RT)
+                    __hip_atomic_store(xb_ + (size_t)c * RT + lane,
+                                       ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(mine),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool want = lane < RT * C;    // gather: lane = r*C + member
+                const unsigned long long* src = xb_ + (want ? (size_t)(lane % C) * RT + (lane / C) : 0);
+                unsigned long long gv = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = !want || ((unsigned)(gv >> 32) == epoch);
+                    if (__all(ok)) break;
+                    if (++spins > sc.spin_limit) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                v = want ? __uint_as_float((unsigned)gv) : 0.0f;
+                v = wave_tree_n(v, C);
+                blk = C;
+            }
+            const int gr_ = lane / blk;
+            const bool lead = (lane % blk == 0) && gr_ < RT;
+            const float n2 = nrm[t];
+            const float sv = (n2 > 0.0f) ? v / n2 : 0.0f;
+            const bool rvalid = lead && (row0 + gr_ < p.Ng);
+            const int64_t growl = (int64_t)g * p.Ng + (rvalid ? row0 + gr_ : p.Ng - 1);
+            int id;
+            const float q = quantize(p.qc, sv, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
+            if (lead) qs[par * (RT + 1) + gr_] = q;
+            if (rvalid && c == 0) store_q(p, growl, t, q, id);
+            if (lane == 0) {
+                qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
+                if (timed_out) {
+                    atomicExch(sc.status, 1);
+                    sc.status[1] = (int)t; sc.status[2] = tile; sc.status[3] = c;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
+        if (COOP) dead = qs[par * (RT + 1) + RT] != 0.0f;
+    }
+}
+
+}  // namespace gpfq
