@@ -103,7 +103,6 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl)
             // rounds of work if the grid does not cover the chip are not modelled: fewer workgroups than CUs
             // simply leave CUs idle, which costs nothing per step
             double cost = slab_step_cost(RT, per_cu * NW, C);
-            if (RT == 4 && NW > 8) cost += 1.2;      // the 12-wave RT=4 variant spills registers
             if (!found || cost < best - 1e-9) {
                 found = true;
                 best = cost;
@@ -170,15 +169,14 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     if (requested == GPFQ_PLAN_RESIDENT || (requested == GPFQ_PLAN_AUTO && pl.S <= kMaxResidentSegments)) {
         pl.kind = GPFQ_PLAN_RESIDENT;
         pl.waves = pl.S;
-        // rows per workgroup: share the activation registers between rows once there are more rows than the
-        // chip has room for one-row workgroups (the roomier variants exist for <= 8 waves)
-        pl.RT = 1;
+        // rows per workgroup: two rows share the column registers once there are more rows than CUs -- two
+        // one-row workgroups on a CU each pull every column through the CU's ~70 GB/s L2 port and become
+        // load-bound (N = 512, m = 7168: 1.33 us per column against 1.16; m = 3072: 0.77 against 0.75), while with
+        // at most one workgroup per CU the shorter step of the one-row variant wins (N = 256, m = 7168: 0.93
+        // against 1.13).  The two-row variant exists for <= 8 waves.
+        pl.RT = (Ng > cus && pl.S <= 8) ? 2 : 1;
         const int force_rt = env_int("GPFQ_RESIDENT_RT", 0);
-        if (pl.S <= 8) {
-            // measured (tools/layer_bench.py): one row per workgroup is never slower than two or four on the
-            // ResNet-50 shapes; the larger variants exist for experiments (GPFQ_RESIDENT_RT)
-            if (force_rt == 1 || force_rt == 2 || force_rt == 4) pl.RT = force_rt;
-        }
+        if (pl.S <= 8 && (force_rt == 1 || force_rt == 2)) pl.RT = force_rt;
         *out = pl;
         return GPFQ_OK;
     }
@@ -250,51 +248,74 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     return sp;
 }
 
-template <int RT, int MODE, bool COOP, int MAXW>
-int launch_slab_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, void* scratch, hipStream_t st)
+template <int RT, int MODE, int MAXW, int DEPTH>
+int launch_coop_t(const Plan& pl, const gpfq::SlabParams& sp, void* scratch, hipStream_t st)
 {
     if (pl.waves > MAXW) return fail(GPFQ_ERR_UNSUPPORTED, "internal: waves exceed the kernel variant's bound");
     // one more wave for the reducer role when the variant's register budget allows it
     const int nwaves = pl.waves + ((pl.waves + 1 <= MAXW && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
     const int threads = 64 * nwaves;
     const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1) + 2 * RT * 64);
-    hipError_t e;
-    dim3 grid;
-    if (COOP) {
-        const int nblocks = pl.tiles * pl.C;
-        // every workgroup must be resident at once: check the grid against the occupancy query (the query is
-        // known to over-report by one only near the SGPR limit of >= 6 waves per SIMD; these kernels run at
-        // <= 4, so the answer is taken as is -- and every spin is bounded anyway)
-        int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>, threads, shm);
-        if (e != hipSuccess) return hip_fail(e, "occupancy query");
-        const int cus = device_cu_count();
-        const int need = (nblocks + cus - 1) / cus;
-        if (nb < 1 || need > nb || (need * nwaves + 3) / 4 > 4)
-            return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
-        size_t xbytes = (size_t)pl.tiles * 2 * pl.C * RT * sizeof(unsigned long long);
-        xbytes = (xbytes + 15) & ~(size_t)15;
-        if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
-        e = hipMemsetAsync(scratch, 0, xbytes, st);
-        if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
-        grid = dim3((unsigned)nblocks, 1, 1);
-    } else {
-        grid = dim3((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
-    }
-    hipLaunchKernelGGL((gpfq::gpfq_slab_kernel<RT, MODE, COOP, MAXW>), grid, dim3((unsigned)threads), shm, st, sp);
+    const int nblocks = pl.tiles * pl.C;
+    // every workgroup must be resident at once: check the grid against the occupancy query (the query is
+    // known to over-report by one only near the SGPR limit of >= 6 waves per SIMD; these kernels run at
+    // <= 4, so the answer is taken as is -- and every spin is bounded anyway)
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_coop_kernel<RT, MODE, MAXW, DEPTH>, threads, shm);
+    if (e != hipSuccess) return hip_fail(e, "occupancy query");
+    const int cus = device_cu_count();
+    const int need = (nblocks + cus - 1) / cus;
+    if (nb < 1 || need > nb || (need * nwaves + 3) / 4 > 4)
+        return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
+    size_t xbytes = (size_t)pl.tiles * 2 * pl.C * RT * sizeof(unsigned long long);
+    xbytes = (xbytes + 15) & ~(size_t)15;
+    if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
+    e = hipMemsetAsync(scratch, 0, xbytes, st);
+    if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
+    hipLaunchKernelGGL((gpfq::gpfq_coop_kernel<RT, MODE, MAXW, DEPTH>), dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, sp);
     e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "GPFQ slab kernel launch");
+    if (e != hipSuccess) return hip_fail(e, "GPFQ cooperative kernel launch");
     return GPFQ_OK;
 }
 
-template <int RT, bool COOP, int MAXW>
-int launch_slab_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, void* scratch, hipStream_t st)
+template <int RT, int MAXW, int DEPTH>
+int launch_coop_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
     switch (mode) {
-    case gpfq::MODE_SOFT: return launch_slab_t<RT, gpfq::MODE_SOFT, COOP, MAXW>(pl, sp, groups, scratch, st);
-    case gpfq::MODE_HARD: return launch_slab_t<RT, gpfq::MODE_HARD, COOP, MAXW>(pl, sp, groups, scratch, st);
-    case gpfq::MODE_STOCHASTIC: return launch_slab_t<RT, gpfq::MODE_STOCHASTIC, COOP, MAXW>(pl, sp, groups, scratch, st);
-    default: return launch_slab_t<RT, gpfq::MODE_MSQ, COOP, MAXW>(pl, sp, groups, scratch, st);
+    case gpfq::MODE_SOFT: return launch_coop_t<RT, gpfq::MODE_SOFT, MAXW, DEPTH>(pl, sp, scratch, st);
+    case gpfq::MODE_HARD: return launch_coop_t<RT, gpfq::MODE_HARD, MAXW, DEPTH>(pl, sp, scratch, st);
+    case gpfq::MODE_STOCHASTIC: return launch_coop_t<RT, gpfq::MODE_STOCHASTIC, MAXW, DEPTH>(pl, sp, scratch, st);
+    default: return launch_coop_t<RT, gpfq::MODE_MSQ, MAXW, DEPTH>(pl, sp, scratch, st);
+    }
+}
+
+template <int RT, int MODE, int MAXW>
+int launch_resident_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, hipStream_t st)
+{
+    if (pl.waves > MAXW || pl.waves != pl.S) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
+    size_t shm = sizeof(float) * 2 * RT * (size_t)pl.S;
+    dim3 grid((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
+    const int pad = env_int("GPFQ_RESIDENT_LDS_PAD", 0);
+    if (pad > 0) {
+        shm += (size_t)pad;
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&gpfq::gpfq_resident_kernel<RT, MODE, MAXW>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (ea != hipSuccess) return hip_fail(ea, "LDS size attribute");
+    }
+    hipLaunchKernelGGL((gpfq::gpfq_resident_kernel<RT, MODE, MAXW>), grid, dim3((unsigned)(64 * pl.waves)), shm, st, sp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "GPFQ resident kernel launch");
+    return GPFQ_OK;
+}
+
+template <int RT, int MAXW>
+int launch_resident_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, hipStream_t st)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return launch_resident_t<RT, gpfq::MODE_SOFT, MAXW>(pl, sp, groups, st);
+    case gpfq::MODE_HARD: return launch_resident_t<RT, gpfq::MODE_HARD, MAXW>(pl, sp, groups, st);
+    case gpfq::MODE_STOCHASTIC: return launch_resident_t<RT, gpfq::MODE_STOCHASTIC, MAXW>(pl, sp, groups, st);
+    default: return launch_resident_t<RT, gpfq::MODE_MSQ, MAXW>(pl, sp, groups, st);
     }
 }
 
@@ -330,17 +351,22 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
         return GPFQ_OK;
     }
     if (pl.kind == GPFQ_PLAN_RESIDENT) {
-        if (pl.RT == 1) return launch_slab_m<1, false, 16>(pl, sp, m, groups, scratch, st);
-        if (pl.RT == 2) return launch_slab_m<2, false, 8>(pl, sp, m, groups, scratch, st);
-        return launch_slab_m<4, false, 8>(pl, sp, m, groups, scratch, st);
+        if (pl.RT == 1) {
+            if (pl.waves <= 8) return launch_resident_m<1, 8>(pl, sp, m, groups, st);
+            if (pl.waves <= 12) return launch_resident_m<1, 12>(pl, sp, m, groups, st);
+            return launch_resident_m<1, 16>(pl, sp, m, groups, st);
+        }
+        return launch_resident_m<2, 8>(pl, sp, m, groups, st);
     }
-    if (pl.RT == 1) return launch_slab_m<1, true, 12>(pl, sp, m, groups, scratch, st);
+    // the last template argument is the look-ahead of the column loads: two steps wherever the five column
+    // buffers fit the variant's register budget
+    if (pl.RT == 1) return launch_coop_m<1, 12, 2>(pl, sp, m, scratch, st);
     if (pl.RT == 2) {
-        if (pl.waves <= 8) return launch_slab_m<2, true, 8>(pl, sp, m, groups, scratch, st);
-        return launch_slab_m<2, true, 12>(pl, sp, m, groups, scratch, st);
+        if (pl.waves <= 8) return launch_coop_m<2, 8, 2>(pl, sp, m, scratch, st);
+        return launch_coop_m<2, 12, 2>(pl, sp, m, scratch, st);
     }
-    if (pl.waves <= 8) return launch_slab_m<4, true, 8>(pl, sp, m, groups, scratch, st);
-    return launch_slab_m<4, true, 12>(pl, sp, m, groups, scratch, st);   // 168-VGPR budget: spills a little
+    if (pl.waves <= 8) return launch_coop_m<4, 8, 2>(pl, sp, m, scratch, st);
+    return launch_coop_m<4, 12, 1>(pl, sp, m, scratch, st);
 }
 
 // most waves per workgroup an instantiation exists for

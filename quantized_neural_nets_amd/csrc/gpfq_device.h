@@ -279,6 +279,17 @@ __device__ __forceinline__ float sweep16(float (&u)[16], const float (&xp)[16], 
     return acc;
 }
 
+// Read-only kernel inputs that every lane reads at the same address (a weight, a column norm) go through the
+// scalar cache: a pointer into the constant address space makes LLVM select s_load_dword.  Left as a plain global
+// pointer they become VECTOR loads as soon as the kernel also stores to global memory (no-clobber cannot be
+// proven), and a dword load at the tail of the in-order vector-memory counter makes its consumer wait for every
+// column load issued before it.
+typedef const float __attribute__((address_space(4))) kfloat;
+__device__ __forceinline__ const kfloat* as_scalar(const float* p)
+{
+    return reinterpret_cast<const kfloat*>(reinterpret_cast<uintptr_t>(p));
+}
+
 __device__ __forceinline__ void load16(float (&dst)[16], const float* __restrict__ p /* + 4*lane applied */)
 {
 #pragma unroll
@@ -286,6 +297,98 @@ __device__ __forceinline__ void load16(float (&dst)[16], const float* __restrict
         float4 v = *reinterpret_cast<const float4*>(p + 256 * c);
         dst[4 * c + 0] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
     }
+}
+
+// ---- column loads whose landing is waited for by hand ---------------------------------------------
+// The register-resident kernels keep the loads of column t+2 in flight across a whole step.  LLVM's vmcnt
+// bookkeeping degrades to vmcnt(0) as soon as the loop body has internal control flow (roles, poll loops, the
+// residual's final store), which serialises every sweep behind the loads issued just before it.  So these loads
+// are inline asm -- invisible to the compiler's counters -- and the consumer waits with an explicit
+// s_waitcnt vmcnt(N) that takes the registers as read-write operands, so that no use can be scheduled above it.
+// Rules that keep this sound:
+//  * a Col16 written by load16_async is not read by anything before wait_landed<N>() names it;
+//  * N counts only the asm loads issued after the wanted ones; vector-memory instructions the compiler knows
+//    about (the Q / idx history stores, the exchange granules) only make a wait stricter, never looser, because
+//    the counter retires in order;
+//  * the kernels that use this must not spill (a spill of an in-flight register would store stale data): the
+//    Makefile's `asm` target prints the spill counts, and tools/check_async_loads.py scans the ISA for copies.
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct Col16 {
+    v4f v[4];                                   // element e = 4*c + j  <->  v[c][j]
+};
+
+__device__ __forceinline__ void zero16(Col16& d)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d.v[c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// base: wave-uniform column pointer (an SGPR pair), lane_off: this lane's byte offset inside the segment (16 * lane).
+// The destination is a read-write operand although nothing is read: that ties the new value to the register of
+// the old one, so a buffer keeps its registers around the unrolled loop and no copy of it is ever needed at the
+// back edge (a copy there would read registers whose loads are still in flight).
+__device__ __forceinline__ void load16_async(Col16& d, const float* base, unsigned lane_off)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(d.v[0]) : "v"(lane_off), "s"(base));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(d.v[1]) : "v"(lane_off), "s"(base));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(d.v[2]) : "v"(lane_off), "s"(base));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "+v"(d.v[3]) : "v"(lane_off), "s"(base));
+}
+
+// the same loads left to the compiler (its own s_waitcnt, safe under register spills): for the one variant that
+// has no room for the look-ahead buffers and spills
+__device__ __forceinline__ void load16_sync(Col16& d, const float* base, unsigned lane_off)
+{
+    const char* q = reinterpret_cast<const char*>(base) + lane_off;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) d.v[c] = *reinterpret_cast<const v4f*>(q + 1024 * c);
+}
+
+// Wait until at most N of this wave's vector-memory operations are outstanding; a and b are usable afterwards.
+// Three parts: the hardware wait; a scheduling barrier, so that nothing -- in particular no register copy that
+// feeds the next statement -- is placed above the wait; and an empty asm that takes the registers as read-write
+// operands, so that every later use depends on it.
+template <int N>
+__device__ __forceinline__ void wait_landed(Col16& a, Col16& b)
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]),
+                 "+v"(b.v[3]));
+}
+template <int N>
+__device__ __forceinline__ void wait_landed(Col16& a)
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]));
+}
+
+// sweep16 on Col16 operands (same operations, same order)
+template <bool SUB>
+__device__ __forceinline__ float sweep16(float (&u)[16], const Col16& xp, const Col16& a, const Col16& x, float qprev, float w)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float uu = u[e];
+        if (SUB) {
+            float p = qprev * xp.v[e >> 2][e & 3];
+            uu = uu - p;
+        }
+        float pa = w * a.v[e >> 2][e & 3];
+        uu = uu + pa;
+        u[e] = uu;
+        acc = __builtin_fmaf(uu, x.v[e >> 2][e & 3], acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ const float* uniform_ptr(const float* p)
+{
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
 }
 
 }  // namespace gpfq

@@ -71,9 +71,8 @@ __device__ __forceinline__ void store_u16(const float (&u)[16], float* __restric
 // reduces the 64 lane chains (wave_tree64); wave 0 then finishes the canonical slot tree, divides by the
 // column norm, quantizes (the RT rows in RT different lanes) and hands q back through LDS.
 //
-//   resident (COOP = false): one workgroup holds whole rows (S <= 16 segments).  HBM/L2 traffic per step is
-//     only x_{t+1}, a_{t+1}, prefetched behind the reduction of step t.
-//   cooperative (COOP = true): a row is split by columns over C workgroups ("members"), needed when rows are
+//   resident: one workgroup holds whole rows (S <= 16 segments) -- gpfq_resident_kernel below.
+//   cooperative (gpfq_coop_kernel): a row is split by columns over C workgroups ("members"), needed when rows are
 //     too long for one workgroup's registers or too few to fill the chip.  Each member reduces its own
 //     aligned block of the slot tree, publishes RT partial sums as 8-byte {value, epoch} granules (one
 //     write-through store each: the data is the flag), gathers the C*RT <= 64 granules of its row tile with
@@ -103,9 +102,9 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 }
 
 // The reducer's serial section of one step (one wave, EXEC full): finish this workgroup's block of the slot tree
-// for all RT rows at once (lane = row*nl + slot), exchange with the other members when cooperative, divide by the
+// for all RT rows at once (lane = row*nl + slot), exchange with the other members, divide by the
 // column norm, quantize the RT rows in RT lanes, hand q back through LDS and write Q / idx.
-template <int RT, int MODE, bool COOP>
+template <int RT, int MODE>
 __device__ __forceinline__ void reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int rlane, int lane, int tile, int c, int C, int par,
                                         int t, float n2cur, int row0, int64_t grow0, int seg_lo)
@@ -119,8 +118,8 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
         v = wave_tree_n(v, nl);
     }
     bool timed_out = false;
-    int blk = nl;                            // lanes r*blk .. r*blk+blk-1 hold row r's value
-    if (COOP) {
+    int blk;                                 // lanes r*blk .. r*blk+blk-1 hold row r's value
+    {
         const unsigned epoch = (unsigned)t + 1u;
         unsigned long long* xb_ = p.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
         if ((lane % nl) == 0 && rlane < RT)
@@ -177,7 +176,7 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
             }
         }
     }
-    if (COOP && lane == 0) {
+    if (lane == 0) {
         qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
         if (timed_out) {
             atomicExch(p.status, 1);
@@ -186,78 +185,118 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
     }
 }
 
+// store_u16 for a residual that is a Col16-free float[16]: see above.  Shared tail of the register-resident
+// kernels: the pending subtraction of the last step, then the residual leaves the registers (step_algorithm.py:148).
+template <int RT>
+__device__ __forceinline__ void finish_rows(const SlabParams& p, float (&u)[RT][16], const float (&qprev)[RT], const Col16& xlast,
+                                            int row0, int64_t grow0, int64_t kbase)
+{
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float pq = qprev[r] * xlast.v[e >> 2][e & 3];
+            u[r][e] = u[r][e] - pq;
+        }
+        if (row0 + r < p.Ng) {
+            float* Urow = p.U + (grow0 + r) * p.ldu;
+            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
+            else store_u16<false>(u[r], Urow, kbase, p.m);
+        }
+    }
+}
+
 // MAXW = most waves per workgroup the instantiation may be launched with; it sets the register budget
 // (16 waves -> 128 VGPRs, 12 -> 168, 8 -> 256): more rows per workgroup need the roomier variants.
-template <int RT, int MODE, bool COOP, int MAXW>
-__global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p)
+// DEPTH = look-ahead of the column loads in steps.  DEPTH 2: three x buffers and two a buffers rotate by name in a
+// six-fold unrolled loop (x_t in X[t % 3], a_t in A[t % 2]), column t+2 is requested behind barrier 2 of step t into
+// the registers sweep t has finished with, and sweep t+1 waits for column t+1 only (vmcnt(8): the eight loads of
+// column t+2 stay in flight).  With 12 waves a workgroup pulls 96 KB of columns per step, which at the ~70 GB/s a
+// CU gets from L2 takes longer than the rest of the step unless it never pauses.  The loads sit BEHIND the
+// exchange on purpose: the granule store and the polls travel through the same per-CU vector-memory queue and
+// would wait for every column load issued before them.  DEPTH 1 (the variant without room for five buffers): two x
+// buffers, one a buffer, requested behind barrier 1 and awaited in full by the next sweep.
+template <int RT, int MODE, int MAXW, int DEPTH>
+__global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p)
 {
-    extern __shared__ float smem[];                 // seg[2][RT][NW], then qs[2][RT + 1]
+    extern __shared__ float smem[];                 // seg[2][RT][NW], then qs[2][RT + 1], then the Q / idx history
     const int NW = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int S = p.S, C = COOP ? p.C : 1;
+    const int S = p.S, C = p.C;
     const int P = pow2_ceil(S);
-    int tile, c, g;
-    if (COOP) {
-        g = 0;
-        // keep the members of one row tile on one XCD when the tile count allows it (blocks b and b+8 share an
-        // XCD under round-robin dispatch; speed only, never correctness)
-        if ((p.tiles & 7) == 0) {
-            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-            tile = (j / C) * 8 + xcd;
-            c = j % C;
-        } else {
-            tile = blockIdx.x / C;
-            c = blockIdx.x % C;
-        }
+    int tile, c;
+    // keep the members of one row tile on one XCD when the tile count allows it (blocks b and b+8 share an
+    // XCD under round-robin dispatch; speed only, never correctness)
+    if ((p.tiles & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (j / C) * 8 + xcd;
+        c = j % C;
     } else {
-        tile = blockIdx.x; c = 0; g = blockIdx.y;
+        tile = blockIdx.x / C;
+        c = blockIdx.x % C;
     }
     const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
     const int n_own = seg_hi - seg_lo;              // <= max_own
     const int max_own = (S + C - 1) / C;            // sweep waves of the fullest member
     // The reducer (slot tree, exchange, quantizer) is a wave of its own when the launch has one to spare
-    // (NW == max_own + 1): its serial section is then not delayed by its own column loads; otherwise wave 0
-    // doubles as the reducer.
+    // (NW == max_own + 1); otherwise wave 0 doubles as the reducer.
     const int rwave = NW > max_own ? max_own : 0;
     const bool active = wave < n_own;
     const int myseg = seg_lo + (active ? wave : 0);
     const int nl = P / C;                           // slots of this workgroup's block; RT*nl <= 64 (host guarantees it)
-    // wave 0 reduces all RT rows at once: lane = r*nl + slot
     const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane % nl, nl);
     const int rlane = lane / nl;                    // row whose slot this lane holds (>= RT: idle)
 
     float* segs = smem;                             // [2][RT][NW]
-    float* qs = smem + 2 * RT * NW;                 // [2][RT + 1] (last = abort flag), then the Q / idx history [2*RT][64]
+    float* qs = smem + 2 * RT * NW;                 // [2][RT + 1] (last = abort flag), then the history [2*RT][64]
 
-    const int row0 = tile * RT;                     // row inside the group
-    const int64_t grow0 = (int64_t)g * p.Ng + row0; // global row of this tile's first row
+    const int row0 = tile * RT;
+    const int64_t grow0 = row0;                     // groups == 1
     const int64_t kbase = (int64_t)myseg * kSeg + 4 * lane;
-    const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
-    const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
-    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+    const float* xload = uniform_ptr(p.XT + (int64_t)myseg * kSeg);      // wave-uniform column pointers
+    const float* aload = uniform_ptr(p.AT + (int64_t)myseg * kSeg);
+    const unsigned lane_off = 16u * (unsigned)lane;
+    const kfloat* nrm = as_scalar(p.nrm2);
 
     float u[RT][16];
-    const float* __restrict__ wrow[RT];
+    const kfloat* wrow[RT];
+    float qprev[RT], wcur[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
-        wrow[r] = p.W + gr * p.ldw;
+        wrow[r] = as_scalar(p.W + gr * p.ldw);
 #pragma unroll
         for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;   // a non-zero initial residual is the streaming plan's job
+        qprev[r] = 0.0f;
+        wcur[r] = wrow[r][0];
     }
-    float qprev[RT], wcur[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) { qprev[r] = 0.0f; wcur[r] = wrow[r][0]; }
     float n2cur = nrm[0];
 
-    // xc = x_t, xo = x_{t-1} (all zero at t = 0, where q_{-1} = 0), aa = a_t
-    float xc[16], xo[16], aa[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { xc[e] = 0.0f; xo[e] = 0.0f; aa[e] = 0.0f; }
-    if (active) { load16(xc, xcol); load16(aa, acol); }
+    Col16 X0, X1, X2, A0, A1;                       // X2, A1 unused (and optimised away) at DEPTH 1
+    zero16(X0); zero16(X1); zero16(X2); zero16(A0); zero16(A1);
+    if constexpr (DEPTH == 2) {
+        // x_0 -> X0, a_0 -> A0, x_1 -> X1, a_1 -> A1 (a one-column layer re-reads column 0); X2 = x_{-1} = 0
+        if (active) {
+            load16_async(X0, xload, lane_off);
+            load16_async(A0, aload, lane_off);
+        }
+        const int64_t adv = (1 < p.d) ? p.m_pad : 0;
+        xload += adv;
+        aload += adv;
+        if (active) {
+            load16_async(X1, xload, lane_off);
+            load16_async(A1, aload, lane_off);
+        }
+    } else {
+        // x_0 -> X0, a_0 -> A0; X1 = x_{-1} = 0
+        if (active) {
+            load16_sync(X0, xload, lane_off);
+            load16_sync(A0, aload, lane_off);
+        }
+    }
 
 #ifdef GPFQ_STAMPS
-    // diagnostic build only: cycles per phase, summed by wave 0 (and the last wave) of block 0 into status[16..]
+    // diagnostic build only: cycles per phase, summed by the reducer wave and one sweep wave of block 0 into status[16..]
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_prev = 0;
 #define GPFQ_STAMP(i)                                                                                   \
@@ -269,15 +308,14 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
         stamp_sum[i] += now_ - stamp_prev;                                                              \
         stamp_prev = now_;                                                                              \
     }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #else
 #define GPFQ_STAMP(i)
 #endif
-    bool dead = false;
     int t = 0;
-#ifdef GPFQ_STAMPS
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-#endif
-    while (t < p.d && !dead) {
+    bool dead = false;
+    // one step; xprev = x_{t-1}, xcur = x_t, acur = a_t.  Returns false after the last column or on a timeout.
+    auto step = [&](Col16& xprev, Col16& xcur, Col16& acur) -> bool {
         GPFQ_STAMP(0)
         const int par = t & 1;
         const bool more = t + 1 < p.d;
@@ -285,10 +323,16 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
         float wn[RT], n2n = 0.0f;
 #pragma unroll
         for (int r = 0; r < RT; ++r) wn[r] = 0.0f;
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
+            n2n = nrm[t + 1];
+        }
         if (active) {
+            if constexpr (DEPTH == 2) wait_landed<8>(xcur, acur);   // column t; the loads of column t+1 stay in flight
             float acc[RT];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r]);
+            for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xprev, acur, xcur, qprev[r], wcur[r]);
             GPFQ_STAMP(1)
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
@@ -297,68 +341,226 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_slab_kernel(const SlabParams p
             }
             GPFQ_STAMP(2)
         }
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
-            n2n = nrm[t + 1];
-        }
         __syncthreads();
         GPFQ_STAMP(3)
-        // Next column's loads, issued OFF the critical path (the sweep waves idle until the reducer is done) and
-        // landing in the registers the sweep just finished with.  The opaque asm keeps LLVM from hoisting them
-        // (they depend on nothing here): hoisted above the sweep they need 32 more VGPRs and a copy that waits
-        // for them before the barrier, and their issue stalls (~60-180 cycles each) sit on the critical path.
         auto issue_loads = [&]() {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) xo[e] = xc[e];
-            int64_t adv = more ? p.m_pad : 0;        // the last step re-reads its own column: no join copy
-            asm volatile("" : "+s"(adv)::"memory");
-            xcol += adv;
-            acol += adv;
-            load16(xc, xcol);
-            load16(aa, acol);
+            // the pointers advance in every wave (uniform values must not change under a per-wave condition, or
+            // they stop being scalar); the last steps re-read the last column rather than branch
+            int64_t adv = (t + DEPTH < p.d) ? p.m_pad : 0;
+            if constexpr (DEPTH == 1) asm volatile("" : "+s"(adv)::"memory");   // keeps LLVM from hoisting its loads above the sweep
+            xload += adv;
+            aload += adv;
+            if (active) {
+                if constexpr (DEPTH == 2) {
+                    load16_async(xprev, xload, lane_off);
+                    load16_async(acur, aload, lane_off);
+                } else {
+                    load16_sync(xprev, xload, lane_off);
+                    load16_sync(acur, aload, lane_off);
+                }
+            }
         };
-        if (active && wave != rwave) issue_loads();
+        if constexpr (DEPTH == 1) issue_loads();    // one step of look-ahead only: they cannot wait for the exchange
         if (wave == rwave) {
             GPFQ_STAMP(4)
-            reducer_section<RT, MODE, COOP>(p, seg, qs, smap, NW, nl, rlane, lane, tile, c, C, par, t, n2cur, row0, grow0,
+            reducer_section<RT, MODE>(p, seg, qs, smap, NW, nl, rlane, lane, tile, c, C, par, t, n2cur, row0, grow0,
                                             seg_lo);
             GPFQ_STAMP(5)
         }
-        if (active && wave == rwave) issue_loads();
         GPFQ_STAMP(6)
         __syncthreads();
         GPFQ_STAMP(7)
+        if constexpr (DEPTH == 2) issue_loads();
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
-        if (COOP) dead = qs[par * (RT + 1) + RT] != 0.0f;
+        if (qs[par * (RT + 1) + RT] != 0.0f) { dead = true; return false; }   // an exchange timed out: status word is set
+        if (!more) return false;
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
         ++t;
+        return true;
+    };
+    int k = 0;                                       // buffer that holds x_t when the loop ends
+    if constexpr (DEPTH == 2) {
+        for (;;) {
+            k = 0; if (!step(X2, X0, A0)) break;
+            k = 1; if (!step(X0, X1, A1)) break;
+            k = 2; if (!step(X1, X2, A0)) break;
+            k = 0; if (!step(X2, X0, A1)) break;
+            k = 1; if (!step(X0, X1, A0)) break;
+            k = 2; if (!step(X1, X2, A1)) break;
+        }
+    } else {
+        for (;;) {
+            k = 0; if (!step(X1, X0, A0)) break;
+            k = 1; if (!step(X0, X1, A0)) break;
+        }
+    }
+    // every load issued above has landed before the buffers are looked at again
+    if constexpr (DEPTH == 2) {
+        wait_landed<0>(X0, X1);
+        wait_landed<0>(X2, A0);
+        wait_landed<0>(A1);
     }
 #ifdef GPFQ_STAMPS
-    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == rwave || wave == (rwave == 0 ? NW - 1 : 0)) && p.status) {
+    if (blockIdx.x == 0 && lane == 0 && (wave == rwave || wave == (rwave == 0 ? NW - 1 : 0)) && p.status) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 16) + (wave == rwave ? 0 : 8);
         for (int i = 0; i < 8; ++i) dbg[i] = stamp_sum[i];
     }
 #endif
     if (dead || !active) return;
+    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row0, grow0, kbase);
+    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row0, grow0, kbase);
+    else finish_rows<RT>(p, u, qprev, X2, row0, grow0, kbase);
+}
 
-    // pending subtraction of the last step, then write the residual (step_algorithm.py:148)
+// ------------------------------------------------------------------------------------------------
+// Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE
+// barrier per step.  Every wave leaves its segment sum in LDS, and after the barrier every wave finishes the
+// slot tree, divides and quantizes for itself (the same bits in every wave), so q never travels through LDS and
+// there is no second barrier.  The column loads run two steps ahead as in gpfq_coop_kernel (DEPTH 2), requested
+// right behind the barrier, so the vector-memory pipe never drains (at ~70 GB/s per CU the columns, n*8 KB per
+// step, are the other bound of this kernel).
+// ------------------------------------------------------------------------------------------------
+template <int RT, int MODE, int MAXW>
+__global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabParams p)
+{
+    extern __shared__ float smem[];                 // seg[2][RT][S]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int S = p.S;                              // == waves of the workgroup
+    const int P = pow2_ceil(S);                     // slots of the canonical tree; RT * P <= 64
+    const int tile = blockIdx.x, g = blockIdx.y;
+    const SlotMap smap = make_slot_map(S, P, 0, 1, lane % P, P);
+    const int rlane = lane / P;                     // row whose slot this lane holds (>= RT: idle)
+    const int row0 = tile * RT;
+    const int64_t grow0 = (int64_t)g * p.Ng + row0;
+    const int64_t kbase = (int64_t)wave * kSeg + 4 * lane;
+    const float* xload = uniform_ptr(p.XT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
+    const float* aload = uniform_ptr(p.AT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
+    const unsigned lane_off = 16u * (unsigned)lane;
+    const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
+
+    float u[RT][16];
+    const kfloat* wrow[RT];
+    float qprev[RT], wcur[RT], qhist[RT];
+    int ihist[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
+        const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
+        wrow[r] = as_scalar(p.W + gr * p.ldw);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float pq = qprev[r] * xo[e];       // xo = x_{d-1} after the last rotation
-            u[r][e] = u[r][e] - pq;
-        }
-        if (row0 + r < p.Ng) {
-            float* Urow = p.U + (grow0 + r) * p.ldu;
-            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
-            else store_u16<false>(u[r], Urow, kbase, p.m);
-        }
+        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
+        qprev[r] = 0.0f; qhist[r] = 0.0f; ihist[r] = 0;
+        wcur[r] = wrow[r][0];
     }
+    float n2cur = nrm[0];
+
+    // x_t lives in X[t % 3], a_t in A[t % 2]; X2 starts as x_{-1} = 0 (q_{-1} = 0)
+    Col16 X0, X1, X2, A0, A1;
+    zero16(X2);
+    load16_async(X0, xload, lane_off);
+    load16_async(A0, aload, lane_off);
+    {
+        const int64_t adv = (1 < p.d) ? p.m_pad : 0;   // a one-column layer re-reads column 0
+        xload += adv;
+        aload += adv;
+    }
+    load16_async(X1, xload, lane_off);
+    load16_async(A1, aload, lane_off);
+
+    int t = 0;
+    // one step; xprev = x_{t-1}, xcur = x_t, acur = a_t.  Returns false after the last column.
+    auto step = [&](Col16& xprev, Col16& xcur, Col16& acur) -> bool {
+        const bool more = t + 1 < p.d;
+        float* seg = smem + (t & 1) * RT * S;
+        float wn[RT], n2n = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = 0.0f;
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
+            n2n = nrm[t + 1];
+        }
+        wait_landed<8>(xcur, acur);                 // column t; the eight loads of column t+1 stay in flight
+        float acc[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xprev, acur, xcur, qprev[r], wcur[r]);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float sg = wave_tree64_lane63(acc[r]);
+            if (lane == 63) seg[r * S + wave] = sg;
+        }
+        const int64_t growl = grow0 + ((rlane < RT && row0 + rlane < p.Ng) ? rlane : 0);
+        float uni = 0.0f;
+        if (MODE == MODE_STOCHASTIC) uni = philox_uniform(p.seed, p.row_id0 + (uint64_t)growl, (uint64_t)t);
+        __syncthreads();
+        // column t+2 into the registers the sweep has just finished with (x_{t-1}'s and a_t's); the last two steps
+        // re-read the last column rather than branch
+        {
+            const int64_t adv = (t + 2 < p.d) ? p.m_pad : 0;
+            xload += adv;
+            aload += adv;
+            load16_async(xprev, xload, lane_off);
+            load16_async(acur, aload, lane_off);
+        }
+        // the slot tree of all RT rows at once (lane = row * P + slot), in every wave
+        const float val = seg[(rlane < RT ? rlane : 0) * S + smap.s0];
+        float v = ((smap.mask & 1u) && rlane < RT) ? val : 0.0f;
+        v = wave_tree_n(v, P);
+        const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+        int id;
+        float q;
+        if (MODE == MODE_SOFT) q = quant_soft(p.step, sarg, p.Kf, p.lamb, id);
+        else if (MODE == MODE_HARD) q = quant_hard(p.step, sarg, p.Kf, p.lamb, id);
+        else if (MODE == MODE_STOCHASTIC) q = quant_stochastic(p.step, sarg, p.Kf, uni, id);
+        else q = quant_msq(p.step, sarg, p.Kf, id);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), r * P));
+            const int idr = __builtin_amdgcn_readlane(id, r * P);
+            if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+        }
+        // Q / idx: 64 steps of history in registers (lane l holds step t0 + l), one coalesced store per row
+        if (((t & 63) == 63 || !more) && wave == 0) {
+            const int t0 = t & ~63;
+            if (lane <= t - t0) {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (row0 + r < p.Ng) {
+                        const int64_t gw = grow0 + r;
+                        p.Q[gw * p.ldq + t0 + lane] = qhist[r];
+                        if (p.idx) {
+                            if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)ihist[r];
+                            else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)ihist[r];
+                        }
+                    }
+                }
+            }
+        }
+        if (!more) return false;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+        n2cur = n2n;
+        ++t;
+        return true;
+    };
+    int k = 0;                                       // buffer that holds x_t when the loop ends (t % 3)
+    for (;;) {
+        k = 0; if (!step(X2, X0, A0)) break;
+        k = 1; if (!step(X0, X1, A1)) break;
+        k = 2; if (!step(X1, X2, A0)) break;
+        k = 0; if (!step(X2, X0, A1)) break;
+        k = 1; if (!step(X0, X1, A0)) break;
+        k = 2; if (!step(X1, X2, A1)) break;
+    }
+    // every load issued above has landed before the buffers are looked at again
+    wait_landed<0>(X0, X1);
+    wait_landed<0>(X2, A0);
+    wait_landed<0>(A1);
+    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row0, grow0, kbase);
+    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row0, grow0, kbase);
+    else finish_rows<RT>(p, u, qprev, X2, row0, grow0, kbase);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -382,14 +584,14 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
     const int64_t kbase = 4 * lane;
     const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
     const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
-    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+    const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
 
     float u[RT][16], xc[16], xo[16], aa[16];
-    const float* __restrict__ wrow[RT];
+    const kfloat* wrow[RT];
     float qprev[RT], wcur[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-        wrow[r] = p.W + (grow0 + ((row0 + r < p.Ng) ? r : 0)) * p.ldw;   // rows past the end duplicate the first
+        wrow[r] = as_scalar(p.W + (grow0 + ((row0 + r < p.Ng) ? r : 0)) * p.ldw);   // rows past the end duplicate the first
 #pragma unroll
         for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
         qprev[r] = 0.0f;
@@ -523,7 +725,8 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCo
     const int64_t row0 = (int64_t)tile * RT;
     const float* __restrict__ ATg = p.AT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
     const float* __restrict__ XTg = p.XT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
-    const float* __restrict__ nrm = p.nrm2 + (int64_t)g * p.d;
+    const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
+    const kfloat* Wk = as_scalar(p.W);
 
     int64_t grow[RT];
     bool valid[RT];
@@ -542,7 +745,7 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCo
         const int par = (int)(t & 1);
         float w[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) w[r] = last ? 0.0f : p.W[grow[r] * p.ldw + t];
+        for (int r = 0; r < RT; ++r) w[r] = last ? 0.0f : Wk[grow[r] * p.ldw + t];
         float* seg = segs + (size_t)par * RT * n_max;
         for (int s = seg_lo + wave; s < seg_hi; s += NW) {
             const int64_t kbase = (int64_t)s * kSeg + 4 * lane;

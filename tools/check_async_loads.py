@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Static check of the hand-waited column loads (gpfq_device.h: load16_async / wait_landed).
+
+The register-resident kernels issue their column loads as inline asm and wait for them with explicit
+`s_waitcnt vmcnt(N)` statements.  That is only sound if nothing touches a destination register of such a load
+while the load may still be in flight -- in particular nothing the compiler adds on its own (a copy, a spill, a
+temporary parked in the register).  This script replays the ISA of those kernels
+(`make -C quantized_neural_nets_amd/csrc asm` writes it to csrc/build/) in program order:
+
+  * an inline-asm `global_load_dwordx4 vD, ...` puts the registers of vD in flight, in issue order;
+  * an inline-asm `s_waitcnt vmcnt(N)` lands every load except the N youngest asm loads (the counter retires in
+    order; loads and stores the compiler issues itself only make the hardware wait longer);
+  * any other instruction that names a register in flight -- as a source or as a destination -- is an error, and
+    so is any scratch access (a spill) in such a kernel.
+
+The unrolled loop body is replayed twice, the second time starting from the state at the bottom of the loop, so
+that registers in flight across the back edge are covered.
+
+    python tools/check_async_loads.py [path/to/gpfq_capi-hip-amdgcn-amd-amdhsa-gfx950.s]
+"""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT = os.path.join(ROOT, "quantized_neural_nets_amd", "csrc", "build", "gpfq_capi-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def regs_of(tok):
+    """v12 -> {12}; v[4:7] -> {4,5,6,7}; anything else -> {}"""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def vregs(line):
+    body = line.split(";")[0]
+    out = set()
+    for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", body):
+        out |= regs_of(tok)
+    return out
+
+
+def dead_result(lines, no):
+    """True if the SGPR written by the instruction at `no` is overwritten before anything reads it."""
+    dst = lines[no].split()[1].rstrip(",")
+    pat = re.compile(r"\b%s\b" % re.escape(dst))
+    wide = re.compile(r"s\[(\d+):(\d+)\]")
+    num = int(dst[1:])
+    for ln in lines[no + 1:no + 1500]:
+        st = ln.split(";")[0].strip()
+        if not st or st.startswith(".") or st.endswith(":"):
+            continue
+        toks = st.replace(",", " ").split()
+        covers = [t for t in toks[1:] if pat.fullmatch(t) or any(int(a) <= num <= int(b) for a, b in wide.findall(t))]
+        if not covers:
+            continue
+        first = toks[1]
+        only_dst = (pat.fullmatch(first) or any(int(a) <= num <= int(b) for a, b in wide.findall(first))) and len(covers) == 1
+        return bool(only_dst) and not toks[0].startswith(("s_cmp", "s_store", "s_cbranch", "v_cmp", "global_store", "ds_write"))
+    return False
+
+
+def replay(name, lines, inflight, problems, report):
+    in_asm = False
+    for no, ln in enumerate(lines):
+        st = ln.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if st.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not st or st.startswith((";", ".")) or st.endswith(":"):
+            continue
+        if in_asm and st.startswith("global_load_dwordx4"):
+            dst = regs_of(st.split()[1].rstrip(","))
+            busy = set().union(*inflight) if inflight else set()
+            if report and dst & busy:
+                problems.append("%s: line %d loads into register(s) still in flight %s: %s" % (name, no, sorted(dst & busy), st))
+            inflight.append(dst)
+            continue
+        if in_asm and st.startswith("s_waitcnt"):
+            m = re.search(r"vmcnt\((\d+)\)", st)
+            if m:
+                n = int(m.group(1))
+                del inflight[:max(0, len(inflight) - n)]
+            continue
+        if st.startswith("scratch_"):
+            if report:
+                problems.append("%s: line %d spills in a kernel with hand-waited loads: %s" % (name, no, st))
+            continue
+        if not inflight:
+            continue
+        busy = set().union(*inflight)
+        hit = vregs(st) & busy
+        if hit and st.startswith("v_readfirstlane_b32") and dead_result(lines, no):
+            continue        # LLVM materialises an undef SGPR as readfirstlane of whatever VGPR; the result is never read
+        if hit and report:
+            problems.append("%s: line %d touches register(s) in flight %s: %s" % (name, no, sorted(hit), st))
+
+
+def check_kernel(name, lines):
+    if not any(l.strip().startswith("global_load_dwordx4") and lines[i - 1].strip().startswith(";;#ASMSTART")
+               for i, l in enumerate(lines) if i > 0):
+        return False, []
+    problems = []
+    inflight = []
+    replay(name, lines, inflight, problems, True)
+    # second pass from the loop-bottom state: only the loop body matters, duplicates are dropped below
+    seen = set(problems)
+    again = []
+    replay(name, lines, inflight, again, True)
+    problems += [p for p in again if p not in seen and "loads into register(s) still in flight" not in p]
+    return True, problems
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else DEFAULT
+    text = open(path).read().split("\n")
+    kernels = {}
+    cur = None
+    for ln in text:
+        m = re.match(r"^(_ZN4gpfq\w+):", ln)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif cur is not None:
+            kernels[cur].append(ln)
+            if ln.strip().startswith("s_endpgm"):
+                cur = None
+    bad = []
+    checked = 0
+    for name, lines in kernels.items():
+        has, problems = check_kernel(name, lines)
+        if has:
+            checked += 1
+            bad += problems
+    for b in bad:
+        print(b)
+    print("%d kernels with hand-waited loads checked, %d problem(s)" % (checked, len(bad)))
+    return 1 if bad or checked == 0 else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
