@@ -85,10 +85,16 @@ def kernel_name(desc):
     kv = dict(x.split("=") for x in w[1:] if "=" in x)
     rt, waves = int(kv["RT"]), int(kv["waves"])
     if w[0] == "resident":
-        return "gpfq_slab_kernel<%d, 0, false, %d>" % (rt, 16 if rt == 1 else 8)
+        if int(kv.get("S", "0")) == 1:
+            return "gpfq_wave_kernel<"
+        return "gpfq_resident_kernel<%d, 0, %d>" % (rt, (8 if waves <= 8 else 12 if waves <= 12 else 16) if rt == 1 else 8)
     if w[0] == "coop":
-        return "gpfq_slab_kernel<%d, 0, true, %d>" % (rt, 12 if (rt == 1 or waves > 8) else 8)
-    return "gpfq_stream_kernel<%d, true>" % rt
+        if rt == 1:
+            return "gpfq_coop_kernel<1, 0, 12, 2>"
+        if rt == 2 or waves <= 8:
+            return "gpfq_coop_kernel<%d, 0, %d, 2>" % (rt, 8 if waves <= 8 else 12)
+        return "gpfq_coop_kernel<4, 0, 12, 1>"
+    return "gpfq_stream_kernel<%d, true" % rt
 
 
 def pmc_traffic(kernel):

@@ -169,12 +169,12 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     if (requested == GPFQ_PLAN_RESIDENT || (requested == GPFQ_PLAN_AUTO && pl.S <= kMaxResidentSegments)) {
         pl.kind = GPFQ_PLAN_RESIDENT;
         pl.waves = pl.S;
-        // rows per workgroup: two rows share the column registers once there are more rows than CUs -- two
-        // one-row workgroups on a CU each pull every column through the CU's ~70 GB/s L2 port and become
-        // load-bound (N = 512, m = 7168: 1.33 us per column against 1.16; m = 3072: 0.77 against 0.75), while with
-        // at most one workgroup per CU the shorter step of the one-row variant wins (N = 256, m = 7168: 0.93
-        // against 1.13).  The two-row variant exists for <= 8 waves.
-        pl.RT = (Ng > cus && pl.S <= 8) ? 2 : 1;
+        // rows per workgroup: two rows share the column registers once there are more rows than CUs AND the rows are
+        // long -- two one-row workgroups on a CU each pull every column through the CU's L2 port and become
+        // load-bound (N = 512, m = 7168: 1.28 us per column against 1.20), while short rows (m = 3072: 0.69 against
+        // 0.76) and at most one workgroup per CU (N = 256, m = 7168: 0.72 against 1.11) favour the shorter step of
+        // the one-row variant.  The two-row variant exists for <= 8 waves.
+        pl.RT = (Ng > cus && pl.S >= 5 && pl.S <= 8) ? 2 : 1;
         const int force_rt = env_int("GPFQ_RESIDENT_RT", 0);
         if (pl.S <= 8 && (force_rt == 1 || force_rt == 2)) pl.RT = force_rt;
         *out = pl;

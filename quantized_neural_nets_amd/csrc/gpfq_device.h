@@ -335,6 +335,14 @@ __device__ __forceinline__ void load16_async(Col16& d, const float* base, unsign
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "+v"(d.v[3]) : "v"(lane_off), "s"(base));
 }
 
+// one quarter (chunk Q: 4 of the 16 elements) of the same loads, for kernels that spread a column's requests over
+// the step instead of queueing eight at once
+template <int Q>
+__device__ __forceinline__ void load4_async(Col16& d, const float* base, unsigned lane_off)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d.v[Q]) : "v"(lane_off), "s"(base), "n"(1024 * Q));
+}
+
 // the same loads left to the compiler (its own s_waitcnt, safe under register spills): for the one variant that
 // has no room for the look-ahead buffers and spills
 __device__ __forceinline__ void load16_sync(Col16& d, const float* base, unsigned lane_off)

@@ -486,6 +486,22 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
         float acc[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xprev, acur, xcur, qprev[r], wcur[r]);
+        // Column t+2 goes into the registers the sweep has just finished with (x_{t-1}'s and a_t's), two requests at
+        // a time at four points of the step: eight at once from every wave fill the CU's vector-memory queue, and a
+        // wave whose request is not accepted stalls right there, on the critical path (the last two steps re-read
+        // the last column rather than branch).
+        {
+            const int64_t adv = (t + 2 < p.d) ? p.m_pad : 0;
+            xload += adv;
+            aload += adv;
+        }
+        constexpr bool kSpread = (RT == 1);          // (with two rows LLVM answers split requests -- per quarter or per
+                                                     //  buffer -- with copies of registers in flight: that variant asks
+                                                     //  for the whole column behind the barrier)
+        if constexpr (kSpread) {
+            load4_async<0>(xprev, xload, lane_off);
+            load4_async<0>(acur, aload, lane_off);
+        }
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const float sg = wave_tree64_lane63(acc[r]);
@@ -494,13 +510,15 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
         const int64_t growl = grow0 + ((rlane < RT && row0 + rlane < p.Ng) ? rlane : 0);
         float uni = 0.0f;
         if (MODE == MODE_STOCHASTIC) uni = philox_uniform(p.seed, p.row_id0 + (uint64_t)growl, (uint64_t)t);
+        if constexpr (kSpread) {
+            load4_async<1>(xprev, xload, lane_off);
+            load4_async<1>(acur, aload, lane_off);
+        }
         __syncthreads();
-        // column t+2 into the registers the sweep has just finished with (x_{t-1}'s and a_t's); the last two steps
-        // re-read the last column rather than branch
-        {
-            const int64_t adv = (t + 2 < p.d) ? p.m_pad : 0;
-            xload += adv;
-            aload += adv;
+        if constexpr (kSpread) {
+            load4_async<2>(xprev, xload, lane_off);
+            load4_async<2>(acur, aload, lane_off);
+        } else {
             load16_async(xprev, xload, lane_off);
             load16_async(acur, aload, lane_off);
         }
@@ -537,6 +555,10 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
                     }
                 }
             }
+        }
+        if constexpr (kSpread) {
+            load4_async<3>(xprev, xload, lane_off);
+            load4_async<3>(acur, aload, lane_off);
         }
         if (!more) return false;
 #pragma unroll
