@@ -328,6 +328,14 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
             for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
             n2n = nrm[t + 1];
         }
+        // the pointers advance in every wave (uniform values must not change under a per-wave condition, or they
+        // stop being scalar); the last steps re-read the last column rather than branch
+        {
+            int64_t adv = (t + DEPTH < p.d) ? p.m_pad : 0;
+            if constexpr (DEPTH == 1) asm volatile("" : "+s"(adv)::"memory");   // keeps LLVM from hoisting its loads above the sweep
+            xload += adv;
+            aload += adv;
+        }
         if (active) {
             if constexpr (DEPTH == 2) wait_landed<8>(xcur, acur);   // column t; the loads of column t+1 stay in flight
             float acc[RT];
@@ -339,28 +347,33 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
                 const float sg = wave_tree64_lane63(acc[r]);
                 if (lane == 63) seg[r * NW + wave] = sg;
             }
+            // Column t+2 into the registers sweep t has finished with (x_{t-1}'s and a_t's): three quarters here,
+            // the last one behind barrier 2.  Measured on the ResNet-50 shapes against every other split that the
+            // build's ISA check accepts: all eight requests behind barrier 2 (the queue is empty for the exchange,
+            // but every wave then stalls issuing into a full queue before its next sweep) 2.45 / 1.84 / 2.33 us per
+            // column, this split 2.30 / 1.74 / 2.28; all of them here 2.61 / 1.75 / 2.27 (the granule store and the
+            // polls of the exchange travel through the same per-CU queue and wait for every request ahead of them).
+            // Requests right behind the sweep make LLVM copy registers that are in flight (RT >= 2): rejected by
+            // tools/check_async_loads.py.
+            if constexpr (DEPTH == 2) {
+                load4_async<0>(xprev, xload, lane_off);
+                load4_async<0>(acur, aload, lane_off);
+                load4_async<1>(xprev, xload, lane_off);
+                load4_async<1>(acur, aload, lane_off);
+                load4_async<2>(xprev, xload, lane_off);
+                load4_async<2>(acur, aload, lane_off);
+            }
             GPFQ_STAMP(2)
         }
         __syncthreads();
         GPFQ_STAMP(3)
-        auto issue_loads = [&]() {
-            // the pointers advance in every wave (uniform values must not change under a per-wave condition, or
-            // they stop being scalar); the last steps re-read the last column rather than branch
-            int64_t adv = (t + DEPTH < p.d) ? p.m_pad : 0;
-            if constexpr (DEPTH == 1) asm volatile("" : "+s"(adv)::"memory");   // keeps LLVM from hoisting its loads above the sweep
-            xload += adv;
-            aload += adv;
+        if constexpr (DEPTH == 1) {
+            // one step of look-ahead only, compiler-managed: the loads cannot wait for the exchange
             if (active) {
-                if constexpr (DEPTH == 2) {
-                    load16_async(xprev, xload, lane_off);
-                    load16_async(acur, aload, lane_off);
-                } else {
-                    load16_sync(xprev, xload, lane_off);
-                    load16_sync(acur, aload, lane_off);
-                }
+                load16_sync(xprev, xload, lane_off);
+                load16_sync(acur, aload, lane_off);
             }
-        };
-        if constexpr (DEPTH == 1) issue_loads();    // one step of look-ahead only: they cannot wait for the exchange
+        }
         if (wave == rwave) {
             GPFQ_STAMP(4)
             reducer_section<RT, MODE>(p, seg, qs, smap, NW, nl, rlane, lane, tile, c, C, par, t, n2cur, row0, grow0,
@@ -370,7 +383,12 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
         GPFQ_STAMP(6)
         __syncthreads();
         GPFQ_STAMP(7)
-        if constexpr (DEPTH == 2) issue_loads();
+        if constexpr (DEPTH == 2) {
+            if (active) {
+                load4_async<3>(xprev, xload, lane_off);
+                load4_async<3>(acur, aload, lane_off);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
         if (qs[par * (RT + 1) + RT] != 0.0f) { dead = true; return false; }   // an exchange timed out: status word is set
