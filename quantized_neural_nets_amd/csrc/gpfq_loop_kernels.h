@@ -1,6 +1,6 @@
-// gpfq_loop_kernels.h -- the GPFQ loop kernels (gfx950): gpfq_slab_kernel (residual resident in registers, whole rows
-// or rows split over co-operating workgroups), gpfq_wave_kernel (one-segment rows, one wave per row tile) and
-// gpfq_stream_kernel (residual streamed through HBM / L2).  Reference: StepAlgorithm._quantization,
+// gpfq_loop_kernels.h -- the GPFQ loop kernels (gfx950): gpfq_resident_kernel (residual resident in registers, whole
+// rows per workgroup), gpfq_coop_kernel (the same with rows split over co-operating workgroups), gpfq_wave_kernel
+// (one-segment rows, one wave per row tile) and gpfq_stream_kernel (residual streamed through HBM / L2).  Reference: StepAlgorithm._quantization,
 // step_algorithm.py:107-148.  One launch runs the WHOLE column loop of a layer (all groups): rows of the residual U
 // are independent, and per step a workgroup makes ONE pass over its rows, fusing
 //   u -= q_{t-1} x_{t-1};  u += w_t a_t;  <u, x_t>.
@@ -64,14 +64,15 @@ __device__ __forceinline__ void store_u16(const float (&u)[16], float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Slab plans (resident / cooperative): the residual lives in registers for the whole column loop.
+// Register-resident plans (resident / cooperative): the residual lives in registers for the whole column loop.
 //
 // A workgroup owns an RT x (n_own segments) slab of U: RT rows sharing the activation registers, one wave
 // per canonical segment.  Per step: every wave sweeps its segment (fused update + fma chain, sweep16) and
-// reduces the 64 lane chains (wave_tree64); wave 0 then finishes the canonical slot tree, divides by the
-// column norm, quantizes (the RT rows in RT different lanes) and hands q back through LDS.
+// reduces the 64 lane chains (wave_tree64_lane63); then the canonical slot tree is finished, the sum divided by the
+// column norm and quantized (the RT rows in RT different lanes).
 //
-//   resident: one workgroup holds whole rows (S <= 16 segments) -- gpfq_resident_kernel below.
+//   resident: one workgroup holds whole rows (S <= 16 segments); every wave finishes the tree for itself, one
+//     barrier per step -- gpfq_resident_kernel below.
 //   cooperative (gpfq_coop_kernel): a row is split by columns over C workgroups ("members"), needed when rows are
 //     too long for one workgroup's registers or too few to fill the chip.  Each member reduces its own
 //     aligned block of the slot tree, publishes RT partial sums as 8-byte {value, epoch} granules (one
@@ -185,8 +186,7 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
     }
 }
 
-// store_u16 for a residual that is a Col16-free float[16]: see above.  Shared tail of the register-resident
-// kernels: the pending subtraction of the last step, then the residual leaves the registers (step_algorithm.py:148).
+// Shared tail of the register-resident kernels: the pending subtraction of the last step, then the residual leaves the registers (step_algorithm.py:148).
 template <int RT>
 __device__ __forceinline__ void finish_rows(const SlabParams& p, float (&u)[RT][16], const float (&qprev)[RT], const Col16& xlast,
                                             int row0, int64_t grow0, int64_t kbase)
