@@ -41,6 +41,7 @@ def build_parser():
     p.add_argument('--synthetic', action='store_true', help='random calibration batches instead of the dataset loader')
     p.add_argument('--image_size', default=224, type=int, help='side of the synthetic images')
     p.add_argument('--save_dir', default=None, help='where to torch.save the quantized model (default: not saved)')
+    p.add_argument('--save_packed', default=None, help='write the quantized model as packed alphabet indices + steps to this file')
     return p
 
 
@@ -120,6 +121,11 @@ def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
         name = (f'ds{args.data_set}_b{bits}_batch{bs}_mlpscalar{mlp_s}_cnnscalar{cnn_s}_mlppercentile{mlp_per}'
                 f'_cnnpercentile{cnn_per}_retain_rate{args.retain_rate}_reg{args.regularizer}_lambda{lamb}.pt')
         torch.save(quantized_model, os.path.join(args.save_dir, args.model, name))
+    if args.save_packed:
+        from . import packed
+        info = packed.save(args.save_packed, quantizer)
+        print("Packed checkpoint %s: %d layers, %.2f MB of indices for %.2f MB of fp32 weights"
+              % (args.save_packed, info["layers"], info["packed_bytes"] / 1e6, info["fp32_bytes"] / 1e6))
     if test_loader is not None:
         acc = test_accuracy(quantized_model, test_loader, device, (1, 5))
         print(f'Top-1 / top-5 accuracy of quantized {args.model}: {acc[0]} / {acc[1]}')

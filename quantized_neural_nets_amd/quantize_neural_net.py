@@ -73,6 +73,7 @@ class QuantizeNeuralNet:
         self.quantized_network_layers = []
         extract_layers(self.quantized_network, self.quantized_network_layers)
         self.layer_reports = []     # per-layer dicts (index, errors, step) -- extra, not in the reference
+        self.layer_indices = []     # per-layer alphabet indices + step, what packed.save() writes -- extra
 
     def quantize_network(self):
         '''Quantize every non-ignored Linear/Conv2d layer in registration order; returns the quantized
@@ -113,6 +114,11 @@ class QuantizeNeuralNet:
             print(f'The relative quantization error of layer {layer_idx} is {relative_quantize_error.cpu().numpy()}.\n')
             self.layer_reports.append(dict(layer=layer_idx, quantize_error=float(quantize_error),
                                            relative_quantize_error=float(relative_quantize_error)))
+            last = StepAlgorithm.last_result
+            if last is not None and last.get("idx") is not None:
+                mode = 1 if self.reg == 'L1' else 2 if self.reg == 'L0' else 3 if self.stochastic_quantization else 0
+                self.layer_indices.append(dict(layer=layer_idx, idx=last["idx"].detach().cpu(), step=float(last["step"]),
+                                               K=int(K), mode=mode, lamb=float(self.lamb if self.lamb is not None else 0.0)))
             if LAYER_LOGGING:
                 self._log_layer(layer_idx, W, Q, quantize_adder, relative_adder)
 

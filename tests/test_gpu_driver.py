@@ -135,3 +135,33 @@ def test_cli_alexnet_plumbing_config(capsys):
         assert torch.allclose(k, torch.round(k), atol=1e-3)
     out = capsys.readouterr().out
     assert "Time used for quantization" in out and "Sparsity" in out
+
+
+@pytest.mark.parametrize("ci", [0, 2])
+def test_packed_checkpoint_round_trip_is_bitwise(ci, tmp_path):
+    """packed.save() keeps the alphabet indices + steps; packed.load() rebuilds the quantized network bit for bit
+    (packed on-disk format instead of the fp32 torch.save of main.py:136)."""
+    from quantized_neural_nets_amd import QuantizeNeuralNet, packed
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g5_driver.npz"))
+    meta = json.loads(str(fx["meta"]))["configs"][ci]
+    cfg = meta["cfg"]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(meta["net_seed"])
+    net = gi.toy_net(rng).to(dev)
+    batches = gi.toy_batches(rng, meta["batch"], meta["nlayers"])
+    np.random.seed(meta["np_seed"])
+    quant = QuantizeNeuralNet(net, "toy", meta["batch"], batches, mlp_bits=cfg["bits"], cnn_bits=cfg["bits"],
+                              ignore_layers=[1], mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16,
+                              mlp_percentile=1, cnn_percentile=1, reg=cfg["reg"], lamb=cfg["lamb"],
+                              retain_rate=cfg["retain_rate"], stochastic_quantization=False, device=dev)
+    qnet = quant.quantize_network()
+    path = str(tmp_path / "toy.gpfq")
+    info = packed.save(path, quant)
+    assert info["layers"] == meta["nlayers"] - 1 and info["packed_bytes"] * 4 < info["fp32_bytes"]
+    fresh = gi.toy_net(np.random.default_rng(123))          # same architecture, other weights
+    packed.load(path, fresh)
+    want = qnet.state_dict()
+    got = fresh.state_dict()
+    assert set(want) == set(got)
+    for k in want:
+        assert torch.equal(want[k].cpu(), got[k]), k

@@ -136,3 +136,42 @@ def test_bench_workload_matches_survey_totals():
     assert len(L) == 16 and sum(n * d for _, n, d, _ in L) == 11317248
     assert abs(sum(bw.algorithmic_bytes(n, d, m) for _, n, d, m in L) / 1e12 - 0.837) < 1e-3
     assert {m for *_, m in L} == {93184, 26624, 7168, 3072}
+
+
+@pytest.mark.parametrize("K,mode", [(1, 0), (2, 1), (4, 0), (8, 0), (8, 2), (2, 2), (64, 3), (200, 0)])
+def test_packed_index_fields_round_trip(K, mode):
+    """packed.pack_indices / unpack_indices: n-bit fields for every alphabet size, ragged lengths, range check."""
+    from quantized_neural_nets_amd import packed
+    lo, count = packed.index_range(K, mode)
+    assert count == (2 * (K + 1) + 1 if mode == 2 else 2 * K + 1)
+    g = torch.Generator().manual_seed(K * 10 + mode)
+    for n in (0, 1, 7, 8, 9, 1000, 4099):
+        idx = torch.randint(lo, lo + count, (n,), generator=g)
+        if n >= 2:
+            idx[0], idx[-1] = lo, lo + count - 1
+        data, nbits = packed.pack_indices(idx.to(torch.int16), K, mode)
+        assert data.dtype == torch.uint8
+        if nbits != 16:
+            assert nbits == packed.field_bits(K, mode) and data.numel() == ((n + 7) // 8) * nbits
+        back = packed.unpack_indices(data, nbits, n, K, mode)
+        assert torch.equal(back, idx)
+    with pytest.raises(ValueError):
+        packed.pack_indices(torch.tensor([lo + count]), K, mode)
+
+
+def test_packed_rebuild_equals_oracle_q(oracle_mod):
+    """indices -> packed -> indices -> rebuild_q gives the oracle's Q bit for bit (msq, soft and hard alphabets)."""
+    import golden_inputs as gi
+    from quantized_neural_nets_amd import dist, packed
+    for name in ("g2_8x27x16_msq_b4", "g2_8x27x16_soft_b2", "g2_8x27x16_hard_b4", "g2_16x64x96_msq_b2"):
+        case = gi.CASES[name]
+        W, A, X = gi.make_inputs(case)
+        K = 2 ** (case["bits"] - 1)
+        o = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"],
+                                      case["groups"])
+        mode = 1 if case["reg"] == "L1" else 2 if case["reg"] == "L0" else 0
+        idx = torch.from_numpy(o["idx"].astype(np.int64))
+        data, nbits = packed.pack_indices(idx, K, mode)
+        back = packed.unpack_indices(data, nbits, idx.numel(), K, mode).reshape(idx.shape)
+        q = dist.rebuild_q(back, float(o["step"]), K, mode, float(case["lamb"] or 0.0))
+        assert np.array_equal(q.numpy(), o["Q"])
