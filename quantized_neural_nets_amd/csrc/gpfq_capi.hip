@@ -293,15 +293,8 @@ template <int RT, int MODE, int MAXW>
 int launch_resident_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, hipStream_t st)
 {
     if (pl.waves > MAXW || pl.waves != pl.S) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
-    size_t shm = sizeof(float) * 2 * RT * (size_t)pl.S;
+    const size_t shm = sizeof(float) * 2 * RT * (size_t)pl.S;
     dim3 grid((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
-    const int pad = env_int("GPFQ_RESIDENT_LDS_PAD", 0);
-    if (pad > 0) {
-        shm += (size_t)pad;
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&gpfq::gpfq_resident_kernel<RT, MODE, MAXW>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-        if (ea != hipSuccess) return hip_fail(ea, "LDS size attribute");
-    }
     hipLaunchKernelGGL((gpfq::gpfq_resident_kernel<RT, MODE, MAXW>), grid, dim3((unsigned)(64 * pl.waves)), shm, st, sp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ resident kernel launch");
