@@ -1,7 +1,7 @@
 // gpfq_capi.hip -- host side of the MI355X GPFQ hot path: plan selection, launches and the C ABI of include/gpfq.h.
 //
 // Path (reference = YixuanSeanZhou/Quantized_Neural_Nets, src/):
-//   StepAlgorithm._quantization   step_algorithm.py:107-148   -> gpfq_loop_kernels.h (slab / wave / stream kernels)
+//   StepAlgorithm._quantization   step_algorithm.py:107-148   -> gpfq_loop_kernels.h (resident / coop / wave / stream kernels)
 //   quantizers                    step_algorithm.py:7-104     -> gpfq_device.h quant_*
 //   column reads [:, t], norm     step_algorithm.py:141-144   -> gpfq_prep_kernels.h
 //   conv activation capture       quantize_neural_net.py:334-347 -> gpfq_prep_kernels.h gpfq_gather_patches_kernel
@@ -312,7 +312,8 @@ int launch_resident_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int 
     }
 }
 
-// The instantiated (rows per workgroup, wave bound) pairs -- keep slab_variant_ok() in step with this switch.
+// Launch of the register-resident plans ("slab" = the RT x n block of U a workgroup keeps in registers): the
+// instantiated (rows per workgroup, wave bound) pairs -- keep slab_max_waves() in step with these switches.
 int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec, void* scratch, hipStream_t st)
 {
     const gpfq::SlabParams sp = make_slab_params(pl, p, vec, scratch);
