@@ -1,0 +1,112 @@
+"""tools/check_async_loads.py is the gate that lets the register-resident kernels wait for their column loads by hand
+(DESIGN.md 4.1): the build fails if the ISA touches a register whose inline-asm load may still be in flight.  These
+tests feed it small hand-written ISA fragments: what must pass, and every kind of violation it must catch."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("check_async_loads", os.path.join(ROOT, "tools", "check_async_loads.py"))
+cal = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(cal)
+
+
+def asm_load(dst, off=0):
+    return ["\t;;#ASMSTART", "\tglobal_load_dwordx4 %s, v99, s[8:9] offset:%d" % (dst, off), "\t;;#ASMEND"]
+
+
+def asm_wait(n):
+    return ["\t;;#ASMSTART", "\ts_waitcnt vmcnt(%d)" % n, "\t;;#ASMEND"]
+
+
+def run(lines):
+    has, problems = cal.check_kernel("k", lines + ["\ts_endpgm"])
+    assert has
+    return problems
+
+
+def test_reads_behind_the_wait_pass():
+    body = asm_load("v[0:3]") + asm_load("v[4:7]") + ["\tv_add_f32_e32 v20, v21, v22"] + asm_wait(0) + \
+        ["\tv_pk_mul_f32 v[30:31], v[0:1], v[4:5]"]
+    assert run(body) == []
+
+
+def test_wait_lands_all_but_the_youngest_n():
+    # two batches of two; vmcnt(2) lands the first batch only
+    body = asm_load("v[0:3]") + asm_load("v[4:7]") + asm_load("v[8:11]") + asm_load("v[12:15]") + asm_wait(2) + \
+        ["\tv_fmac_f32_e32 v40, v0, v4"]
+    assert run(body) == []
+    bad = run(body + ["\tv_fmac_f32_e32 v40, v8, v4"])
+    assert len(bad) == 1 and "[8]" in bad[0]
+
+
+def test_copy_of_a_register_in_flight_is_caught():
+    bad = run(asm_load("v[0:3]") + ["\tv_mov_b64_e32 v[50:51], v[2:3]"] + asm_wait(0))
+    assert len(bad) == 1 and "touches register(s) in flight [2, 3]" in bad[0]
+
+
+def test_write_into_a_register_in_flight_is_caught():
+    bad = run(asm_load("v[0:3]") + ["\tv_mov_b32_e32 v1, v60"] + asm_wait(0))
+    assert len(bad) == 1 and "[1]" in bad[0]
+
+
+def test_compiler_waits_do_not_count():
+    # an s_waitcnt the compiler inserted (outside asm markers) lands nothing for the check
+    bad = run(asm_load("v[0:3]") + ["\ts_waitcnt vmcnt(0)", "\tv_add_f32_e32 v9, v0, v0"] + asm_wait(0))
+    assert len(bad) == 1
+
+
+def test_spill_is_caught():
+    bad = run(asm_load("v[0:3]") + asm_wait(0) + ["\tscratch_store_dwordx2 off, v[20:21], off offset:8"])
+    assert len(bad) == 1 and "spills" in bad[0]
+
+
+def test_reload_into_a_buffer_still_in_flight_is_caught():
+    bad = run(asm_load("v[0:3]") + asm_load("v[0:3]", 1024) + asm_wait(0))
+    assert any("still in flight" in b for b in bad)
+
+
+def test_loop_back_edge_is_replayed():
+    # the load at the bottom of the loop is still in flight when the top of the loop is reached again
+    body = ["\tv_add_f32_e32 v30, v0, v1"] + asm_wait(0) + asm_load("v[0:3]")
+    bad = run(body)
+    assert len(bad) == 1 and "touches register(s) in flight [0, 1]" in bad[0]
+
+
+def test_dead_readfirstlane_of_an_undef_is_tolerated():
+    body = asm_load("v[0:3]") + ["\tv_readfirstlane_b32 s26, v0", "\ts_mov_b32 s26, 0"] + asm_wait(0)
+    assert run(body) == []
+    body = asm_load("v[0:3]") + ["\tv_readfirstlane_b32 s26, v0", "\ts_add_u32 s4, s26, 1"] + asm_wait(0)
+    assert len(run(body)) == 1
+
+
+def test_kernels_without_asm_loads_are_skipped():
+    has, problems = cal.check_kernel("k", ["\tglobal_load_dwordx4 v[0:3], v9, s[0:1]", "\tv_mov_b32_e32 v5, v0", "\ts_endpgm"])
+    assert not has and problems == []
+
+
+def test_the_built_isa_passes():
+    """The library in the tree was published by a build whose ISA passed (the Makefile runs the check before it copies
+    the library); re-check the kept ISA so that a hand-built library cannot slip through."""
+    import pytest
+    isa = cal.DEFAULT
+    if not os.path.exists(isa):
+        pytest.skip("no ISA kept (library not built with make in this tree)")
+    lib = os.path.join(ROOT, "quantized_neural_nets_amd", "libgpfq_hip.so")
+    if os.path.exists(lib) and os.path.getmtime(lib) + 5 < os.path.getmtime(isa):
+        pytest.skip("ISA newer than the library: a build is in progress or failed")
+    text = open(isa).read().split("\n")
+    kernels, cur = {}, None
+    for ln in text:
+        if ln.startswith("_ZN4gpfq") and ln.rstrip().endswith(":") or (ln.startswith("_ZN4gpfq") and ":" in ln.split()[0]):
+            cur = ln.split(":")[0]
+            kernels[cur] = []
+        elif cur is not None:
+            kernels[cur].append(ln)
+            if ln.strip().startswith("s_endpgm"):
+                cur = None
+    checked, bad = 0, []
+    for name, lines in kernels.items():
+        has, problems = cal.check_kernel(name, lines)
+        checked += has
+        bad += problems
+    assert checked >= 20 and bad == []
