@@ -87,7 +87,7 @@ def kernel_name(desc):
     if w[0] == "resident":
         if int(kv.get("S", "0")) == 1:
             return "gpfq_wave_kernel<"
-        return "gpfq_resident_kernel<%d, 0, %d>" % (rt, (8 if waves <= 8 else 12 if waves <= 12 else 16) if rt == 1 else 8)
+        return "gpfq_resident_kernel<0, %d>" % (8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
         if rt == 1:
             return "gpfq_coop_kernel<1, 0, 12, 2>"

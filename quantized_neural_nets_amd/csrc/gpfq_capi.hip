@@ -169,14 +169,11 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     if (requested == GPFQ_PLAN_RESIDENT || (requested == GPFQ_PLAN_AUTO && pl.S <= kMaxResidentSegments)) {
         pl.kind = GPFQ_PLAN_RESIDENT;
         pl.waves = pl.S;
-        // rows per workgroup: two rows share the column registers once there are more rows than CUs AND the rows are
-        // long -- two one-row workgroups on a CU each pull every column through the CU's L2 port and become
-        // load-bound (N = 512, m = 7168: 1.28 us per column against 1.20), while short rows (m = 3072: 0.69 against
-        // 0.76) and at most one workgroup per CU (N = 256, m = 7168: 0.72 against 1.11) favour the shorter step of
-        // the one-row variant.  The two-row variant exists for <= 8 waves.
-        pl.RT = (Ng > cus && pl.S >= 5 && pl.S <= 8) ? 2 : 1;
-        const int force_rt = env_int("GPFQ_RESIDENT_RT", 0);
-        if (pl.S <= 8 && (force_rt == 1 || force_rt == 2)) pl.RT = force_rt;
+        // one row per workgroup.  (A two-row variant, sharing the column registers between rows, was 6 % faster for
+        // N = 512, m = 7168 -- two one-row workgroups per CU pull every column twice through the CU's L2 port -- but
+        // LLVM kept answering small source changes with copies of its in-flight column registers, which the build's
+        // ISA check rejects; it was dropped.)
+        pl.RT = 1;
         *out = pl;
         return GPFQ_OK;
     }
@@ -289,26 +286,26 @@ int launch_coop_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* sc
     }
 }
 
-template <int RT, int MODE, int MAXW>
+template <int MODE, int MAXW>
 int launch_resident_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, hipStream_t st)
 {
     if (pl.waves > MAXW || pl.waves != pl.S) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
-    const size_t shm = sizeof(float) * 2 * RT * (size_t)pl.S;
-    dim3 grid((unsigned)((sp.Ng + RT - 1) / RT), (unsigned)groups, 1);
-    hipLaunchKernelGGL((gpfq::gpfq_resident_kernel<RT, MODE, MAXW>), grid, dim3((unsigned)(64 * pl.waves)), shm, st, sp);
+    const size_t shm = sizeof(float) * 2 * (size_t)pl.S;
+    dim3 grid((unsigned)sp.Ng, (unsigned)groups, 1);
+    hipLaunchKernelGGL((gpfq::gpfq_resident_kernel<MODE, MAXW>), grid, dim3((unsigned)(64 * pl.waves)), shm, st, sp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ resident kernel launch");
     return GPFQ_OK;
 }
 
-template <int RT, int MAXW>
+template <int MAXW>
 int launch_resident_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, hipStream_t st)
 {
     switch (mode) {
-    case gpfq::MODE_SOFT: return launch_resident_t<RT, gpfq::MODE_SOFT, MAXW>(pl, sp, groups, st);
-    case gpfq::MODE_HARD: return launch_resident_t<RT, gpfq::MODE_HARD, MAXW>(pl, sp, groups, st);
-    case gpfq::MODE_STOCHASTIC: return launch_resident_t<RT, gpfq::MODE_STOCHASTIC, MAXW>(pl, sp, groups, st);
-    default: return launch_resident_t<RT, gpfq::MODE_MSQ, MAXW>(pl, sp, groups, st);
+    case gpfq::MODE_SOFT: return launch_resident_t<gpfq::MODE_SOFT, MAXW>(pl, sp, groups, st);
+    case gpfq::MODE_HARD: return launch_resident_t<gpfq::MODE_HARD, MAXW>(pl, sp, groups, st);
+    case gpfq::MODE_STOCHASTIC: return launch_resident_t<gpfq::MODE_STOCHASTIC, MAXW>(pl, sp, groups, st);
+    default: return launch_resident_t<gpfq::MODE_MSQ, MAXW>(pl, sp, groups, st);
     }
 }
 
@@ -345,12 +342,9 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
         return GPFQ_OK;
     }
     if (pl.kind == GPFQ_PLAN_RESIDENT) {
-        if (pl.RT == 1) {
-            if (pl.waves <= 8) return launch_resident_m<1, 8>(pl, sp, m, groups, st);
-            if (pl.waves <= 12) return launch_resident_m<1, 12>(pl, sp, m, groups, st);
-            return launch_resident_m<1, 16>(pl, sp, m, groups, st);
-        }
-        return launch_resident_m<2, 8>(pl, sp, m, groups, st);
+        if (pl.waves <= 8) return launch_resident_m<8>(pl, sp, m, groups, st);
+        if (pl.waves <= 12) return launch_resident_m<12>(pl, sp, m, groups, st);
+        return launch_resident_m<16>(pl, sp, m, groups, st);
     }
     // the last template argument is the look-ahead of the column loads: two steps wherever the five column
     // buffers fit the variant's register budget
@@ -366,7 +360,7 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
 // most waves per workgroup an instantiation exists for
 int slab_max_waves(bool coop, int RT)
 {
-    if (!coop) return RT == 1 ? 16 : 8;
+    if (!coop) return 16;
     return 12;
 }
 

@@ -90,6 +90,18 @@ __device__ __forceinline__ float wave_tree_n(float v, int nl)
     return v;
 }
 
+// The same tree over one row of 16 lanes whose lanes >= nl hold +0.0f, without the level tests: the extra levels add
+// +0.0f, which is exact for every value except -0.0f -- and a segment sum is never -0.0f (its fma chain starts from
+// +0.0f, and +0.0f + (-0.0f) = +0.0f).  Result in lanes < nl (in fact in all 16).
+__device__ __forceinline__ float wave_tree16_zero_padded(float v)
+{
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    return v;
+}
+
 // ---- canonical second level: segment sums -> slots -> pairwise tree -----------------------------
 // A row of S segments uses P = 2^ceil(log2 S) slots; segment s sits in slot floor(s*P/S).  A lane owns
 // `per` consecutive slots starting at slot_base + lane*per; SlotMap remembers which of them are occupied

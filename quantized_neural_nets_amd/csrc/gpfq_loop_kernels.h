@@ -434,45 +434,43 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE
-// barrier per step.  Every wave leaves its segment sum in LDS, and after the barrier every wave finishes the
-// slot tree, divides and quantizes for itself (the same bits in every wave), so q never travels through LDS and
-// there is no second barrier.  The column loads run two steps ahead as in gpfq_coop_kernel (DEPTH 2), requested
-// right behind the barrier, so the vector-memory pipe never drains (at ~70 GB/s per CU the columns, n*8 KB per
-// step, are the other bound of this kernel).
+// Resident plan (a whole row in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE
+// barrier per step.  Every wave leaves its segment sum in LDS, and behind the barrier every wave finishes the slot
+// tree, divides and quantizes for itself (the same bits in every wave), so q never travels through LDS and there
+// is no second barrier.  The column loads run two steps ahead as in gpfq_coop_kernel (DEPTH 2), two requests at a
+// time at four points of the step: eight at once from every wave fill the CU's vector-memory queue, and a wave
+// whose request is not accepted stalls right there, on the critical path.  The step is a dependent chain of ~1000
+// cycles, so it is also kept free of taken branches (each ~20 cycles): no level tests in the slot tree, no
+// "is there a next column" test, the rare Q / idx flush out of line.
+// One row per workgroup: RT is a template parameter only for the helpers it shares with the cooperative kernel.
 // ------------------------------------------------------------------------------------------------
-template <int RT, int MODE, int MAXW>
+template <int MODE, int MAXW>
 __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabParams p)
 {
-    extern __shared__ float smem[];                 // seg[2][RT][S]
+    constexpr int RT = 1;
+    extern __shared__ float smem[];                 // seg[2][S]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int S = p.S;                              // == waves of the workgroup
-    const int P = pow2_ceil(S);                     // slots of the canonical tree; RT * P <= 64
-    const int tile = blockIdx.x, g = blockIdx.y;
+    const int P = pow2_ceil(S);                     // slots of the canonical tree, <= 16: one DPP row
+    const int row = blockIdx.x, g = blockIdx.y;
     const SlotMap smap = make_slot_map(S, P, 0, 1, lane % P, P);
-    const int rlane = lane / P;                     // row whose slot this lane holds (>= RT: idle)
-    const int row0 = tile * RT;
-    const int64_t grow0 = (int64_t)g * p.Ng + row0;
+    const bool occupied = (smap.mask & 1u) && lane < P;          // lanes >= P contribute +0.0f
+    const int64_t grow = (int64_t)g * p.Ng + row;
     const int64_t kbase = (int64_t)wave * kSeg + 4 * lane;
     const float* xload = uniform_ptr(p.XT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const float* aload = uniform_ptr(p.AT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const unsigned lane_off = 16u * (unsigned)lane;
     const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
+    const kfloat* wrow = as_scalar(p.W + grow * p.ldw);
+    // "this is wave 0" as a scalar, so that the flush test of the Q / idx history is a scalar branch
+    const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
 
     float u[RT][16];
-    const kfloat* wrow[RT];
-    float qprev[RT], wcur[RT], qhist[RT];
-    int ihist[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
-        wrow[r] = as_scalar(p.W + gr * p.ldw);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
-        qprev[r] = 0.0f; qhist[r] = 0.0f; ihist[r] = 0;
-        wcur[r] = wrow[r][0];
-    }
-    float n2cur = nrm[0];
+    for (int e = 0; e < 16; ++e) u[0][e] = 0.0f;
+    float qprev[RT] = {0.0f}, wcur = wrow[0], n2cur = nrm[0];
+    float qhist = 0.0f;
+    int ihist = 0;
 
     // x_t lives in X[t % 3], a_t in A[t % 2]; X2 starts as x_{-1} = 0 (q_{-1} = 0)
     Col16 X0, X1, X2, A0, A1;
@@ -491,59 +489,33 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
     // one step; xprev = x_{t-1}, xcur = x_t, acur = a_t.  Returns false after the last column.
     auto step = [&](Col16& xprev, Col16& xcur, Col16& acur) -> bool {
         const bool more = t + 1 < p.d;
-        float* seg = smem + (t & 1) * RT * S;
-        float wn[RT], n2n = 0.0f;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = 0.0f;
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
-            n2n = nrm[t + 1];
-        }
+        float* seg = smem + (t & 1) * S;
+        // next column's weight and norm through the scalar cache; the last step re-reads its own (unused) pair
+        const int tn = more ? t + 1 : t;
+        const float wn = wrow[tn], n2n = nrm[tn];
         wait_landed<8>(xcur, acur);                 // column t; the eight loads of column t+1 stay in flight
-        float acc[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xprev, acur, xcur, qprev[r], wcur[r]);
-        // Column t+2 goes into the registers the sweep has just finished with (x_{t-1}'s and a_t's), two requests at
-        // a time at four points of the step: eight at once from every wave fill the CU's vector-memory queue, and a
-        // wave whose request is not accepted stalls right there, on the critical path (the last two steps re-read
-        // the last column rather than branch).
+        const float acc = sweep16<true>(u[0], xprev, acur, xcur, qprev[0], wcur);
+        // column t+2 goes into the registers the sweep has just finished with (x_{t-1}'s and a_t's); the last two
+        // steps re-read the last column rather than branch
         {
             const int64_t adv = (t + 2 < p.d) ? p.m_pad : 0;
             xload += adv;
             aload += adv;
         }
-        constexpr bool kSpread = (RT == 1);          // (with two rows LLVM answers split requests -- per quarter or per
-                                                     //  buffer -- with copies of registers in flight: that variant asks
-                                                     //  for the whole column behind the barrier)
-        if constexpr (kSpread) {
-            load4_async<0>(xprev, xload, lane_off);
-            load4_async<0>(acur, aload, lane_off);
-        }
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const float sg = wave_tree64_lane63(acc[r]);
-            if (lane == 63) seg[r * S + wave] = sg;
-        }
-        const int64_t growl = grow0 + ((rlane < RT && row0 + rlane < p.Ng) ? rlane : 0);
+        load4_async<0>(xprev, xload, lane_off);
+        load4_async<0>(acur, aload, lane_off);
+        const float sg = wave_tree64_lane63(acc);
+        if (lane == 63) seg[wave] = sg;
         float uni = 0.0f;
-        if (MODE == MODE_STOCHASTIC) uni = philox_uniform(p.seed, p.row_id0 + (uint64_t)growl, (uint64_t)t);
-        if constexpr (kSpread) {
-            load4_async<1>(xprev, xload, lane_off);
-            load4_async<1>(acur, aload, lane_off);
-        }
+        if (MODE == MODE_STOCHASTIC) uni = philox_uniform(p.seed, p.row_id0 + (uint64_t)grow, (uint64_t)t);
+        load4_async<1>(xprev, xload, lane_off);
+        load4_async<1>(acur, aload, lane_off);
         __syncthreads();
-        if constexpr (kSpread) {
-            load4_async<2>(xprev, xload, lane_off);
-            load4_async<2>(acur, aload, lane_off);
-        } else {
-            load16_async(xprev, xload, lane_off);
-            load16_async(acur, aload, lane_off);
-        }
-        // the slot tree of all RT rows at once (lane = row * P + slot), in every wave
-        const float val = seg[(rlane < RT ? rlane : 0) * S + smap.s0];
-        float v = ((smap.mask & 1u) && rlane < RT) ? val : 0.0f;
-        v = wave_tree_n(v, P);
+        load4_async<2>(xprev, xload, lane_off);
+        load4_async<2>(acur, aload, lane_off);
+        // the slot tree in every wave: lane = slot; lanes >= P hold +0.0f, so the four levels need no tests
+        const float val = seg[smap.s0];             // s0 is a valid segment in every lane
+        const float v = wave_tree16_zero_padded(occupied ? val : 0.0f);
         const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
         int id;
         float q;
@@ -551,36 +523,24 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
         else if (MODE == MODE_HARD) q = quant_hard(p.step, sarg, p.Kf, p.lamb, id);
         else if (MODE == MODE_STOCHASTIC) q = quant_stochastic(p.step, sarg, p.Kf, uni, id);
         else q = quant_msq(p.step, sarg, p.Kf, id);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), r * P));
-            const int idr = __builtin_amdgcn_readlane(id, r * P);
-            if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
-        }
-        // Q / idx: 64 steps of history in registers (lane l holds step t0 + l), one coalesced store per row
-        if (((t & 63) == 63 || !more) && wave == 0) {
+        qprev[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), 0));
+        const int idr = __builtin_amdgcn_readlane(id, 0);
+        // Q / idx: 64 steps of history in registers (lane l holds step t0 + l), one coalesced store every 64 steps
+        if (lane == (t & 63)) { qhist = qprev[0]; ihist = idr; }
+        if (__builtin_expect(((t & 63) == 63 || !more) && wave0, 0)) {
             const int t0 = t & ~63;
             if (lane <= t - t0) {
-#pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    if (row0 + r < p.Ng) {
-                        const int64_t gw = grow0 + r;
-                        p.Q[gw * p.ldq + t0 + lane] = qhist[r];
-                        if (p.idx) {
-                            if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)ihist[r];
-                            else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)ihist[r];
-                        }
-                    }
+                p.Q[grow * p.ldq + t0 + lane] = qhist;
+                if (p.idx) {
+                    if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[grow * p.ldi + t0 + lane] = (int8_t)ihist;
+                    else reinterpret_cast<int16_t*>(p.idx)[grow * p.ldi + t0 + lane] = (int16_t)ihist;
                 }
             }
         }
-        if constexpr (kSpread) {
-            load4_async<3>(xprev, xload, lane_off);
-            load4_async<3>(acur, aload, lane_off);
-        }
+        load4_async<3>(xprev, xload, lane_off);
+        load4_async<3>(acur, aload, lane_off);
         if (!more) return false;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+        wcur = wn;
         n2cur = n2n;
         ++t;
         return true;
@@ -598,9 +558,9 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
     wait_landed<0>(X0, X1);
     wait_landed<0>(X2, A0);
     wait_landed<0>(A1);
-    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row0, grow0, kbase);
-    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row0, grow0, kbase);
-    else finish_rows<RT>(p, u, qprev, X2, row0, grow0, kbase);
+    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row, grow, kbase);
+    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row, grow, kbase);
+    else finish_rows<RT>(p, u, qprev, X2, row, grow, kbase);
 }
 
 // ------------------------------------------------------------------------------------------------

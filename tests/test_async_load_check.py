@@ -72,11 +72,12 @@ def test_loop_back_edge_is_replayed():
     assert len(bad) == 1 and "touches register(s) in flight [0, 1]" in bad[0]
 
 
-def test_dead_readfirstlane_of_an_undef_is_tolerated():
-    body = asm_load("v[0:3]") + ["\tv_readfirstlane_b32 s26, v0", "\ts_mov_b32 s26, 0"] + asm_wait(0)
+def test_readfirstlane_of_an_undef_is_tolerated():
+    # LLVM materialises undef scalars as v_readfirstlane of an arbitrary VGPR, possibly one in flight
+    body = asm_load("v[0:3]") + ["\tv_readfirstlane_b32 s31, v0", "\tv_pk_mul_f32 v[8:9], v[10:11], s[30:31] op_sel_hi:[1,0]"] + asm_wait(0)
     assert run(body) == []
-    body = asm_load("v[0:3]") + ["\tv_readfirstlane_b32 s26, v0", "\ts_add_u32 s4, s26, 1"] + asm_wait(0)
-    assert len(run(body)) == 1
+    # any other scalar read of a register in flight is still an error
+    assert len(run(asm_load("v[0:3]") + ["\tv_readlane_b32 s31, v0, 3"] + asm_wait(0))) == 1
 
 
 def test_kernels_without_asm_loads_are_skipped():

