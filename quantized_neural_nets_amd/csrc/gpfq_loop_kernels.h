@@ -103,33 +103,39 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 }
 
 // The reducer's serial section of one step (one wave, EXEC full): finish this workgroup's block of the slot tree
-// for all RT rows at once (lane = row*nl + slot), exchange with the other members, divide by the
-// column norm, quantize the RT rows in RT lanes, hand q back through LDS and write Q / idx.
+// for all RT rows at once, exchange with the other members, divide by the column norm, quantize the RT rows in RT
+// lanes, hand q back through LDS and write Q / idx.
+// Lane layout: every row owns an aligned block of lanes padded with +0.0f -- 16 lanes (one DPP row) for the member's
+// own slots (nl <= 16 of them: a member has at most 12 segments), `stride` = max(16, C) lanes for the gathered
+// members -- so that both trees run all their levels without testing how many are needed: a taken branch costs
+// ~20 cycles on this chain, and adding +0.0f is exact (a partial sum is never -0.0f, see wave_tree16_zero_padded).
 template <int RT, int MODE>
 __device__ __forceinline__ void reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
-                                        int NW, int nl, int rlane, int lane, int tile, int c, int C, int par,
+                                        int NW, int nl, int lane, int tile, int c, int C, int par,
                                         int t, float n2cur, int row0, int64_t grow0, int seg_lo)
 {
-    // this workgroup's block of the slot tree for all RT rows at once: blocks of nl lanes
+    // this workgroup's block of the slot tree for all RT rows at once: lane = 16 * row + slot
     float v;
     {
-        const int rr = rlane < RT ? rlane : 0;
+        const int r16 = lane >> 4;
+        const int rr = r16 < RT ? r16 : 0;
         const float val = seg[rr * NW + (smap.s0 - seg_lo)];
-        v = ((smap.mask & 1u) && rlane < RT) ? val : 0.0f;
-        v = wave_tree_n(v, nl);
+        v = wave_tree16_zero_padded(((smap.mask & 1u) && r16 < RT) ? val : 0.0f);
     }
     bool timed_out = false;
-    int blk;                                 // lanes r*blk .. r*blk+blk-1 hold row r's value
+    const int sh = C <= 16 ? 4 : (C <= 32 ? 5 : 6);          // log2 of the lane stride of a row in the gather
+    const int gr_ = lane >> sh;              // row of this lane
+    const int member = lane & ((1 << sh) - 1);
     {
         const unsigned epoch = (unsigned)t + 1u;
         unsigned long long* xb_ = p.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
-        if ((lane % nl) == 0 && rlane < RT)
-            __hip_atomic_store(xb_ + (size_t)c * RT + rlane,
+        if ((lane & 15) == 0 && (lane >> 4) < RT)
+            __hip_atomic_store(xb_ + (size_t)c * RT + (lane >> 4),
                                ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // gather: lane = r*C + member
-        const bool want = lane < RT * C;
-        const unsigned long long* src = xb_ + (want ? (size_t)(lane % C) * RT + (lane / C) : 0);
+        // gather: lane = stride * row + member
+        const bool want = member < C && gr_ < RT;
+        const unsigned long long* src = xb_ + (want ? (size_t)member * RT + gr_ : 0);
         unsigned long long gv = 0;
         unsigned spins = 0;
         for (;;) {
@@ -139,12 +145,12 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
             if (++spins > p.spin_limit) { timed_out = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
-        v = want ? __uint_as_float((unsigned)gv) : 0.0f;
-        v = wave_tree_n(v, C);               // upper levels of the slot tree, per aligned block of C lanes
-        blk = C;
+        // upper levels of the slot tree over the members of each row
+        v = wave_tree16_zero_padded(want ? __uint_as_float((unsigned)gv) : 0.0f);
+        if (sh > 4) v = xor16_add(v);
+        if (sh > 5) v = xor32_add(v);
     }
-    const int gr_ = lane / blk;              // row of this lane
-    const bool lead = (lane % blk == 0) && gr_ < RT;
+    const bool lead = member == 0 && gr_ < RT;
     const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
     const bool rvalid = lead && (row0 + gr_ < p.Ng);
     const int64_t growl = grow0 + (rvalid ? gr_ : 0);
@@ -243,9 +249,8 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
     const int rwave = NW > max_own ? max_own : 0;
     const bool active = wave < n_own;
     const int myseg = seg_lo + (active ? wave : 0);
-    const int nl = P / C;                           // slots of this workgroup's block; RT*nl <= 64 (host guarantees it)
-    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane % nl, nl);
-    const int rlane = lane / nl;                    // row whose slot this lane holds (>= RT: idle)
+    const int nl = P / C;                           // slots of this workgroup's block, <= 16 (at most 12 segments per member)
+    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane & 15, nl);   // reducer: lane = 16 * row + slot
 
     float* segs = smem;                             // [2][RT][NW]
     float* qs = smem + 2 * RT * NW;                 // [2][RT + 1] (last = abort flag), then the history [2*RT][64]
@@ -320,14 +325,13 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
         const int par = t & 1;
         const bool more = t + 1 < p.d;
         float* seg = segs + par * RT * NW;
-        float wn[RT], n2n = 0.0f;
+        // next column's weights and norm through the scalar cache; the last step re-reads its own (unused) ones
+        // rather than branch
+        float wn[RT];
+        const int tn = more ? t + 1 : t;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = 0.0f;
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < RT; ++r) wn[r] = wrow[r][t + 1];
-            n2n = nrm[t + 1];
-        }
+        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
+        const float n2n = nrm[tn];
         // the pointers advance in every wave (uniform values must not change under a per-wave condition, or they
         // stop being scalar); the last steps re-read the last column rather than branch
         {
@@ -376,8 +380,7 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
         }
         if (wave == rwave) {
             GPFQ_STAMP(4)
-            reducer_section<RT, MODE>(p, seg, qs, smap, NW, nl, rlane, lane, tile, c, C, par, t, n2cur, row0, grow0,
-                                            seg_lo);
+            reducer_section<RT, MODE>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, row0, grow0, seg_lo);
             GPFQ_STAMP(5)
         }
         GPFQ_STAMP(6)
