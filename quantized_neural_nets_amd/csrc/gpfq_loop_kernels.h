@@ -165,7 +165,7 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
         hist[gr_ * 64 + (t & 63)] = q;
         hist[(RT + gr_) * 64 + (t & 63)] = __int_as_float(id);
     }
-    if ((t & 63) == 63 || t + 1 == p.d) {
+    if (__builtin_expect((t & 63) == 63 || t + 1 == p.d, 0)) {
         const int t0 = t & ~63;
         const int n = t - t0 + 1;                    // steps in this history block
         if (c == 0 && lane < n) {
@@ -185,7 +185,7 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
     }
     if (lane == 0) {
         qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
-        if (timed_out) {
+        if (__builtin_expect(timed_out, 0)) {
             atomicExch(p.status, 1);
             p.status[1] = t; p.status[2] = tile; p.status[3] = c;
         }
