@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
     const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
     const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
 
-    float u[RT][16], xc[16], xo[16], aa[16];
+    float u[RT][16], X0[16], X1[16], A0[16];
     const kfloat* wrow[RT];
     float qprev[RT], wcur[RT];
 #pragma unroll
@@ -600,36 +600,38 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
         qprev[r] = 0.0f;
         wcur[r] = wrow[r][0];
     }
+    // x_t alternates between X0 and X1 (no copies), a_t lives in A0; X1 starts as x_{-1} = 0 (q_{-1} = 0)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) xo[e] = 0.0f;
-    load16(xc, xcol);
-    load16(aa, acol);
+    for (int e = 0; e < 16; ++e) X1[e] = 0.0f;
+    load16(X0, xcol);
+    load16(A0, acol);
     float n2cur = nrm[0];
-    float qh = 0.0f;                                // Q / idx history: lane = (step % 64) * ... one register per row
-    float qhist[RT];
+    float qhist[RT];                                // Q / idx history: lane l holds step t0 + l, one register per row
     int ihist[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) { qhist[r] = 0.0f; ihist[r] = 0; }
-    (void)qh;
-    for (int t = 0; t < p.d; ++t) {
+    int t = 0;
+    // one step; xprev = x_{t-1}, xcur = x_t.  Returns false after the last column.
+    auto step = [&](float (&xprev)[16], float (&xcur)[16]) -> bool {
         const bool more = t + 1 < p.d;
         float acc[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xo, aa, xc, qprev[r], wcur[r]);
-        // next column: issued right behind the sweep (its latency hides under the reduction and the quantizer);
-        // the opaque asm keeps it from being hoisted above the sweep, unconditional so that no join copy is needed
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xo[e] = xc[e];
+        for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xprev, A0, xcur, qprev[r], wcur[r]);
+        // next column into the registers the sweep has just finished with (x_{t-1}'s and a_t's), issued right behind
+        // the sweep (its latency hides under the reduction and the quantizer); the opaque asm keeps it from being
+        // hoisted above the sweep, and it is unconditional (the last step re-reads its own column) so that no join
+        // copy and no branch is needed
         int64_t adv = more ? p.m_pad : 0;
         asm volatile("" : "+s"(adv) : "v"(acc[0]));
         xcol += adv;
         acol += adv;
-        load16(xc, xcol);
-        load16(aa, acol);
+        load16(xprev, xcol);
+        load16(A0, acol);
+        const int tn = more ? t + 1 : t;
         float wn[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = more ? wrow[r][t + 1] : 0.0f;
-        const float n2n = more ? nrm[t + 1] : 0.0f;
+        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
+        const float n2n = nrm[tn];
         // the RT row totals, row r parked in lane r, then ONE quantizer evaluation for all rows
         float v = 0.0f;
 #pragma unroll
@@ -647,7 +649,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
             const int idr = __builtin_amdgcn_readlane(id, r);
             if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
         }
-        if ((t & 63) == 63 || !more) {
+        if (__builtin_expect((t & 63) == 63 || !more, 0)) {
             const int t0 = t & ~63;
             if (lane <= t - t0) {
 #pragma unroll
@@ -663,23 +665,36 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
                 }
             }
         }
+        if (!more) return false;
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
+        ++t;
+        return true;
+    };
+    int k = 0;                                       // buffer that holds x_{d-1} when the loop ends
+    for (;;) {
+        k = 0; if (!step(X1, X0)) break;
+        k = 1; if (!step(X0, X1)) break;
     }
+    // pending subtraction of the last step, then the residual leaves the registers (step_algorithm.py:148)
+    auto finish = [&](const float (&xlast)[16]) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
+        for (int r = 0; r < RT; ++r) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float pq = qprev[r] * xo[e];       // xo = x_{d-1} after the last rotation
-            u[r][e] = u[r][e] - pq;
+            for (int e = 0; e < 16; ++e) {
+                const float pq = qprev[r] * xlast[e];
+                u[r][e] = u[r][e] - pq;
+            }
+            if (row0 + r < p.Ng) {
+                float* Urow = p.U + (grow0 + r) * p.ldu;
+                if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
+                else store_u16<false>(u[r], Urow, kbase, p.m);
+            }
         }
-        if (row0 + r < p.Ng) {
-            float* Urow = p.U + (grow0 + r) * p.ldu;
-            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
-            else store_u16<false>(u[r], Urow, kbase, p.m);
-        }
-    }
+    };
+    if (k == 0) finish(X0);
+    else finish(X1);
 }
 
 struct StreamCoop {
