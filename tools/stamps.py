@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle shares of the slab kernel (needs `make -C quantized_neural_nets_amd/csrc stamps`).
+"""Diagnostic: per-phase cycle shares of the cooperative kernel (needs `make -C quantized_neural_nets_amd/csrc stamps`).
    GPFQ_LIB_OVERRIDE=.../libgpfq_hip_stamps.so python tools/stamps.py N,d,m [ENV=..]"""
 import ctypes, os, sys
 import torch
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench_workload as bw
 from quantized_neural_nets_amd import StepAlgorithm, _lib
-names = ["top/loop", "sweep", "prefetch+tree64+ldsw", "barrier1", "combine", "exchange", "quantize+store", "barrier2"]
+names = ["top (q from LDS, last quarter of the loads)", "wait+sweep", "lane tree + LDS + 3/4 of the loads", "barrier1", "(reducer) enter", "(reducer) slot tree + exchange + quantizer", "leave", "barrier2"]
 dev = torch.device("cuda:0")
 for a in sys.argv[1:]:
     if "=" in a:
