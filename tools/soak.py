@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Randomized soak of the loop kernels against the CPU oracle (GPU box only; test infrastructure, not product).
+Random (N, d, m, groups, mode, bits, plan) cases -- small enough for the oracle -- must agree bit for bit in idx, Q, U.
+    python tools/soak.py [cases=200] [seed=1]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_inputs as gi  # noqa: E402
+from oracle import gpfq_oracle as oracle  # noqa: E402
+from quantized_neural_nets_amd import StepAlgorithm, _lib  # noqa: E402
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    kinds = {}
+    t0 = time.time()
+    bad = 0
+    for ci in range(ncases):
+        fam = rng.choice(["wave", "resident", "coop", "stream", "grouped"])
+        groups = 1
+        if fam == "wave":
+            N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
+        elif fam == "resident":
+            N, m = int(rng.integers(1, 40)), int(rng.integers(1025, 16385))
+        elif fam == "coop":
+            N, m = int(rng.integers(1, 24)), int(rng.integers(16385, 60000))
+        elif fam == "stream":
+            N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
+        else:
+            groups = int(rng.choice([2, 3, 4]))
+            N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
+        d = int(rng.integers(1, 40))
+        bits = int(rng.choice([2, 3, 4]))
+        reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
+        plan = 1 if fam == "stream" else 0
+        case = dict(name="soak%d" % ci, N=N, d=d, m=m, bits=bits, scalar=1.16, percentile=1.0, reg=reg, lamb=0.02,
+                    groups=groups, first_layer=bool(rng.integers(0, 2)), zero_every=int(rng.choice([0, 3, 7])),
+                    seed=int(rng.integers(0, 1 << 30)))
+        W, A, X = gi.make_inputs(case)
+        K = 2 ** (bits - 1)
+        StepAlgorithm.plan = plan
+        try:
+            r = StepAlgorithm._quantize_layer_ex(torch.from_numpy(W).to(dev), torch.from_numpy(A).to(dev),
+                                                 torch.from_numpy(X).to(dev), m, 1.16 / K, K, 1.0, reg, 0.02, groups, False,
+                                                 dev, compute_errors=False)
+            torch.cuda.synchronize()
+            _lib.check_status(dev)
+        finally:
+            StepAlgorithm.plan = 0
+        o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
+        desc = _lib.describe_plan(N, d, m, groups, plan).split()[0]
+        kinds[desc] = kinds.get(desc, 0) + 1
+        ok = (np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+              and np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
+              and np.array_equal(r["U"].cpu().numpy(), o["U"]))
+        if not ok:
+            bad += 1
+            print("MISMATCH", case, desc, flush=True)
+        if ci % 25 == 24:
+            print("%d cases, %d mismatches, %.0f s, plans %s" % (ci + 1, bad, time.time() - t0, kinds), flush=True)
+    print("done: %d cases, %d mismatches, plans %s" % (ncases, bad, kinds))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
