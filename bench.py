@@ -116,12 +116,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="calibration batch (1024 = the BASELINE config)")
+    ap.add_argument("--batch", type=int, default=None, help="calibration batch (default: the workload's named batch; 1024 for the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 stream, 2 resident (debug)")
     ap.add_argument("--layers", default=None, help="substring filter on layer names (debug)")
-    ap.add_argument("--workload", default="r50_3x3", choices=["r50_3x3", "r50_all_convs"],
-                    help="r50_3x3 = the headline config (sixteen 3x3 convs); r50_all_convs = all 53 conv layers (secondary)")
+    ap.add_argument("--workload", default="r50_3x3", choices=sorted(bw.WORKLOADS),
+                    help="r50_3x3 = the headline config (sixteen 3x3 convs at batch 1024); secondary: r50_all_convs (all 53 "
+                         "conv layers), r18 (ResNet-18 at batch 256), vgg16 (VGG-16 at batch 512)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -148,7 +149,10 @@ def main():
         qdist.enable()
     StepAlgorithm.plan = args.plan
 
-    layers = bw.resnet50_3x3_layers(args.batch) if args.workload == "r50_3x3" else bw.resnet50_all_convs(args.batch)
+    layer_fn, named_batch, workload_desc = bw.WORKLOADS[args.workload]
+    if args.batch is None:
+        args.batch = named_batch
+    layers = layer_fn(args.batch)
     if args.layers:
         layers = [l for l in layers if args.layers in l[0]]
     total_weights = sum(N * d for _, N, d, _ in layers)
@@ -254,7 +258,8 @@ def main():
                                          "achieved_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
                                      for k, v in fam.items()}}
         out = {
-            "metric": "M weights quantized/sec (GPFQ loop), ResNet-50 conv layers, calib batch %d" % args.batch,
+            "metric": "M weights quantized/sec (GPFQ loop), %s, calib batch %d"
+                      % ("ResNet-50 conv layers" if args.workload.startswith("r50") else workload_desc.split(" all")[0] + " layers", args.batch),
             "value": round(total_weights * args.steps / elapsed / 1e6, 4),
             "unit": "M weights/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -264,8 +269,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("ResNet-50 sixteen 3x3 conv2 layers" if args.workload == "r50_3x3" else
-                                    "ResNet-50 all 53 conv layers") + ", calibration batch %d, 4-bit (K=8), scalar 1.16, "
+            "config": {"workload": workload_desc + ", calibration batch %d, 4-bit (K=8), scalar 1.16, "
                                    "retain_rate 0.25" % args.batch,
                        "layers": len(layers), "weights": total_weights,
                        "algorithmic_bytes": sum(alg_bytes.values()),

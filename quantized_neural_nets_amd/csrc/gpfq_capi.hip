@@ -70,18 +70,33 @@ int env_int(const char* name, int dflt)
 
 int slab_max_waves(bool coop, int RT);
 
-// Cost model of one column step (microseconds), fitted to MI355X measurements (tools/layer_bench.py): a fixed
-// latency (barriers, reductions, quantizer; plus the granule exchange when cooperative), RT sweeps issued by a
-// wave that owns its SIMD slot, and the per-CU column traffic / issue contention that grows with the waves on a CU.
-double slab_step_cost(int RT, int waves, int C)
+// Cost model of one cooperative column step (microseconds): least squares over 50 measured (N, S, RT, C) points on an
+// MI355X (tools/layer_bench.py sweep over the ResNet-50 cooperative shapes and their 2-, 4- and 8-way row shards; rms
+// error 0.18 us, and it picks the fastest measured configuration for every one of those shapes).  A fixed part
+// (barriers, exchange hop, quantizer), RT sweeps, the column requests of the waves on the CU, and the gather: more
+// than 16 granules (RT * C) cost extra, the more so the more workgroups are exchanging at the same time; 32 members
+// cost extra again; so does the one-step look-ahead of the variant without room for five column buffers.
+double slab_step_cost(int RT, int waves, int C, int wgs)
 {
-    // gathering from 16 / 32 / 64 members costs 0.9 / 2.3 / 4 us more than from <= 8 (measured 0.9 and 2.3)
-    return 0.5 + 0.285 * RT + 0.134 * waves + (C >= 64 ? 4.0 : C >= 32 ? 2.3 : C >= 16 ? 0.9 : 0.0);
+    const int n = RT * C;
+    return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.28 + 1.02 * wgs / 256.0 : 0.0) + (C >= 32 ? 0.65 : 0.0) +
+           (C >= 64 ? 1.5 : 0.0) + ((RT == 4 && waves > 8) ? 0.43 : 0.0);
+}
+
+// The resident plan's column step: one row per workgroup, S waves each, issue-bound per SIMD (0.42 / 0.65 / 1.10 /
+// 1.30 us at 3 / 7 / 12 / 16 waves on a CU, 0.62 / 1.13 at 6 / 14); more rows than fit run in rounds.
+double resident_step_cost(int64_t Ng, int S, int cus)
+{
+    const int fit = 16 / S > 0 ? 16 / S : 1;                       // workgroups of S waves that fit a CU's 16 wave slots
+    int64_t per_cu = (Ng + cus - 1) / cus;
+    const int conc = (int)(per_cu < fit ? per_cu : fit);
+    const int64_t rounds = (Ng + (int64_t)cus * conc - 1) / ((int64_t)cus * conc);
+    return (double)rounds * (0.22 + 0.072 * conc * S);
 }
 
 // Cooperative configuration: cheapest modelled step among the (RT, C) pairs whose grid is co-resident.
 // Depends on (Ng, S, CU count) only -- never on the data.
-bool choose_coop(int64_t Ng, int S, int cus, Plan* pl)
+bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullptr)
 {
     const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
     const int wgs_per_cu = env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1;
@@ -102,7 +117,9 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl)
             if ((per_cu * NW + 3) / 4 > 4) continue;
             // rounds of work if the grid does not cover the chip are not modelled: fewer workgroups than CUs
             // simply leave CUs idle, which costs nothing per step
-            double cost = slab_step_cost(RT, per_cu * NW, C);
+            const int vmax = RT == 1 ? 12 : (NW <= 8 ? 8 : 12);      // wave bound of the variant launch_slab picks
+            const int launched = NW + (NW + 1 <= vmax ? 1 : 0);      // + the reducer wave when it fits
+            double cost = slab_step_cost(RT, per_cu * launched, C, wgs);
             if (!found || cost < best - 1e-9) {
                 found = true;
                 best = cost;
@@ -110,6 +127,7 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl)
             }
         }
     }
+    if (found && cost_out) *cost_out = best;
     return found;
 }
 
@@ -174,6 +192,16 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
         // LLVM kept answering small source changes with copies of its in-flight column registers, which the build's
         // ISA check rejects; it was dropped.)
         pl.RT = 1;
+        // Long rows of which a CU holds only one at a time run in rounds; four rows per cooperative workgroup can then
+        // be cheaper (N = 512, m = 13 312, VGG-16's 512-channel convs at batch 512: 2.39 -> 2.17 us per column).
+        if (requested == GPFQ_PLAN_AUTO && groups == 1 && have_scratch && Ng > cus && !env_int("GPFQ_COOP_DISABLE", 0)) {
+            Plan cp = pl;
+            double ccost = 0.0;
+            if (choose_coop(Ng, pl.S, cus, &cp, &ccost) && ccost < 0.97 * resident_step_cost(Ng, pl.S, cus)) {
+                *out = cp;
+                return GPFQ_OK;
+            }
+        }
         *out = pl;
         return GPFQ_OK;
     }

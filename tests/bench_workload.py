@@ -41,6 +41,48 @@ def resnet50_all_convs(B=1024):
     return layers
 
 
+def resnet18_layers(B=256):
+    """[(name, N, d, m)] for the 21 conv + fc layers of ResNet-18 in extract_layers order (BASELINE.json configs[1]:
+    4-bit, calibration batch 256).  BasicBlock: conv1 (carries the stride), conv2, downsample."""
+    layers = [("conv1", 64, 3 * 49, conv_m(B, 224, 7, 3))]
+    inplanes, H = 64, 56
+    for name, planes, stride in (("layer1", 64, 1), ("layer2", 128, 2), ("layer3", 256, 2), ("layer4", 512, 2)):
+        for b in range(2):
+            s = stride if b == 0 else 1
+            Hout = H // s
+            layers.append(("%s.%d.conv1" % (name, b), planes, inplanes * 9, conv_m(B, H, 3, 1)))
+            layers.append(("%s.%d.conv2" % (name, b), planes, planes * 9, conv_m(B, Hout, 3, 1)))
+            if b == 0 and (s != 1 or inplanes != planes):
+                layers.append(("%s.0.downsample.0" % name, planes, inplanes, conv_m(B, H, 1, 0)))
+            inplanes, H = planes, Hout
+    layers.append(("fc", 1000, 512, B))
+    return layers
+
+
+def vgg16_layers(B=512):
+    """[(name, N, d, m)] for the 13 conv + 3 fc layers of VGG-16 (BASELINE.json configs[2]: 4-bit, calibration
+    batch 512): first convs with m = 720 384 calibration rows, fc6 with 25 088 columns."""
+    layers = []
+    cin, H, i = 3, 224, 0
+    for v in (64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"):
+        if v == "M":
+            H //= 2
+            continue
+        layers.append(("features.conv%d" % i, v, cin * 9, conv_m(B, H, 3, 1)))
+        cin, i = v, i + 1
+    layers += [("classifier.fc6", 4096, 512 * 7 * 7, B), ("classifier.fc7", 4096, 4096, B), ("classifier.fc8", 1000, 4096, B)]
+    return layers
+
+
+WORKLOADS = {
+    # name: (layer list function, named calibration batch, description)
+    "r50_3x3": (resnet50_3x3_layers, 1024, "ResNet-50 sixteen 3x3 conv2 layers"),
+    "r50_all_convs": (resnet50_all_convs, 1024, "ResNet-50 all 53 conv layers"),
+    "r18": (resnet18_layers, 256, "ResNet-18 all 21 conv + fc layers"),
+    "vgg16": (vgg16_layers, 512, "VGG-16 all 16 conv + fc layers"),
+}
+
+
 def algorithmic_bytes(N, d, m, groups=1):
     """per greedy step of one group 8*N_g*m + 8*m + 8*N_g bytes; per layer groups*d_g times that."""
     Ng = N // groups

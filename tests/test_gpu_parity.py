@@ -213,7 +213,7 @@ def test_cooperative_streaming_configurations(qnn, oracle_mod, monkeypatch, rt, 
     assert np.array_equal(r["U"].cpu().numpy(), o["U"])
 
 
-@pytest.mark.parametrize("N,expect", [(8, "coop RT=1 C=8"), (16, "coop RT="), (32, "coop RT=")])
+@pytest.mark.parametrize("N,expect", [(8, "coop RT=1 C=16"), (16, "coop RT="), (32, "coop RT=")])
 def test_eight_gpu_shard_shapes_of_long_rows(qnn, oracle_mod, N, expect):
     """What one rank of an 8-GPU neuron shard sees for ResNet-50 layer1 / layer2.0 at batch 1024 (m = 93 184, a
     few rows), bit-exact against the oracle; plus the widest configuration (32 members per row tile), forced."""

@@ -67,7 +67,9 @@ def test_plan_selection(lib):
     assert lib.describe_plan(128, 1152, 93184).startswith("coop RT=4 C=8 waves=12")
     assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=2 C=4 waves=7")
     assert lib.describe_plan(256, 2304, 26624).startswith("coop RT=4 C=4 waves=7")
-    assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=8 waves=12")        # an 8-GPU shard of 64 rows
+    assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=16 waves=6")        # an 8-GPU shard of 64 rows
+    assert lib.describe_plan(32, 2304, 26624).startswith("coop RT=1 C=8 waves=4")       # an 8-GPU shard of 256 rows
+    assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=4 C=2 waves=7")      # long rows, more rows than CUs
     assert lib.describe_plan(64, 9, 30000, 64).startswith("stream")                     # grouped: never cooperative
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
     with pytest.raises(lib.GpfqError):
@@ -136,6 +138,15 @@ def test_bench_workload_matches_survey_totals():
     assert len(L) == 16 and sum(n * d for _, n, d, _ in L) == 11317248
     assert abs(sum(bw.algorithmic_bytes(n, d, m) for _, n, d, m in L) / 1e12 - 0.837) < 1e-3
     assert {m for *_, m in L} == {93184, 26624, 7168, 3072}
+    # the other configs' models: ResNet-18 at batch 256, VGG-16 at batch 512
+    R = bw.resnet18_layers(256)
+    assert len(R) == 21 and abs(sum(n * d for _, n, d, _ in R) / 1e6 - 11.68) < 0.01
+    assert abs(sum(bw.algorithmic_bytes(n, d, m) for _, n, d, m in R) / 1e12 - 0.213) < 2e-3
+    assert min(m for *_, m in R) == 256 and max(m for *_, m in R) == 200960
+    V = bw.vgg16_layers(512)
+    assert len(V) == 16 and abs(sum(n * d for _, n, d, _ in V) / 1e6 - 138.3) < 0.1
+    assert abs(sum(bw.algorithmic_bytes(n, d, m) for _, n, d, m in V) / 1e12 - 2.449) < 5e-3
+    assert max(m for *_, m in V) == 720384
 
 
 @pytest.mark.parametrize("K,mode", [(1, 0), (2, 1), (4, 0), (8, 0), (8, 2), (2, 2), (64, 3), (200, 0)])
