@@ -26,7 +26,7 @@ def main():
     t0 = time.time()
     bad = 0
     for ci in range(ncases):
-        fam = rng.choice(["wave", "resident", "coop", "stream", "grouped"])
+        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "stream", "grouped"])
         groups = 1
         if fam == "wave":
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
@@ -34,12 +34,14 @@ def main():
             N, m = int(rng.integers(1, 40)), int(rng.integers(1025, 16385))
         elif fam == "coop":
             N, m = int(rng.integers(1, 24)), int(rng.integers(16385, 60000))
+        elif fam == "coop_rows":                    # enough rows for the 2- and 4-row cooperative variants
+            N, m = int(rng.integers(24, 300)), int(rng.integers(16385, 100000))
         elif fam == "stream":
             N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
         else:
             groups = int(rng.choice([2, 3, 4]))
             N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
-        d = int(rng.integers(1, 40))
+        d = int(rng.integers(1, 12 if fam == "coop_rows" else 40))
         bits = int(rng.choice([2, 3, 4]))
         reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
         plan = 1 if fam == "stream" else 0
