@@ -148,6 +148,8 @@ def main():
             td.init_process_group(args.backend)
         qdist.enable()
     StepAlgorithm.plan = args.plan
+    # host threads for the input generation: torchrun pins OMP_NUM_THREADS to 1 per rank; share the cores instead
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // max(world, 1))))
 
     layer_fn, named_batch, workload_desc = bw.WORKLOADS[args.workload]
     if args.batch is None:
