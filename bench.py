@@ -3,60 +3,122 @@
 batch 1024 (BASELINE.json metric), synthetic activations/weights of the named layer shapes.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
+      N > 1 without a torch.distributed environment: bench.py starts `python -m torch.distributed.run
+      --nproc-per-node N bench.py ...` itself, as a CHILD process and before anything touches the GPU, relays the
+      child's JSON line and exits with its return code.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
 
-A "step" is one pass of the hot path over the whole workload: for each of the 16 layers, column preparation
-(transpose + norms) + the GPFQ loop kernel (+ the layer-end RCCL all_gather of the int8 indices when N > 1).
+A "step" is one pass of the hot path over the whole workload: for each layer, column preparation (transpose +
+norms; --capture: the fused patch gather of the real driver instead) + the GPFQ loop kernel (+ the layer-end RCCL
+all_gather of the int8 indices when N > 1) -- through StepAlgorithm._quantize_layer_ex exactly as
+QuantizeNeuralNet.quantize_network() calls it, including the status read behind every cooperative launch.
 Inputs are resident in HBM before the timed region.  With N > 1 the output neurons of every layer are sharded
 across the ranks (strong scaling: total work fixed).  Rank 0 prints ONE JSON line.
+
+After the timed region the outputs of the LAST timed step are checked: every layer's indices against a rerun on the
+streaming kernel family, and the first columns of four layers against the CPU oracle (the same run that is timed as
+the C leg of cpu_baseline).  A mismatch makes the run fail.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import bench_workload as bw  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+L2_PEAK_GBPS = 34500.0      # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(layers, budget_s=20.0):
+def parse_args():
+    import bench_workload as bw
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=None, help="calibration batch (default: the workload's named batch; 1024 for the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-output-check", action="store_true", help="skip the post-run output checks (profiling runs)")
+    ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 stream, 2 resident, 3 cooperative, 4 whole-row stream (debug)")
+    ap.add_argument("--layers", default=None, help="substring filter on layer names (debug)")
+    ap.add_argument("--workload", default="r50_3x3", choices=sorted(bw.WORKLOADS),
+                    help="r50_3x3 = the headline config (sixteen 3x3 convs at batch 1024); secondary: r50_all (all 54 layers), "
+                         "r50_all_convs, r18 (ResNet-18 at batch 256), vgg16 (VGG-16 at batch 512), effnet_b1 (EfficientNet-B1, "
+                         "2-bit, L1, batch 1024)")
+    ap.add_argument("--capture", action="store_true",
+                    help="time the column preparation the way the real driver runs it: the fused conv-patch gather "
+                         "(gpfq_gather_patches_f32) from synthetic feature maps, instead of transposing (m, d) matrices")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--layer-table", default=None, help="also write the per-layer table to this file")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: run the same command under torch.distributed.run in a child process (never an
+    exec: this process may not touch the GPU first, and does not), relay its stdout, return its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log("bench.py: --gpus %d without a torch.distributed environment: launching %s" % (args.gpus, " ".join(cmd[1:9]) + " ..."))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{"):
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    elif rc == 0:
+        rc = 1
+        log("bench.py: the distributed child printed no JSON line")
+    return rc
+
+
+def cpu_baseline(data, gpu_idx, budget_s=20.0):
     """The reference's per-step op sequence (torch ops, oracle/gpfq_oracle.py torch_restatement_quantization)
     and the C oracle, timed on this box's host cores on a bounded sample: the first columns of four of the
-    workload's layer shapes, as many as fit in budget_s/4 seconds each (at least 8).  torch gets
-    min(cores, 16) threads: with one thread per core of a 256-core host the reference's small ops crawl."""
+    workload's layers (the SAME inputs the GPU just quantized), as many as fit in budget_s/4 seconds each (at least 8).
+    torch gets min(cores, 16) threads: with one thread per core of a 256-core host the reference's small ops crawl.
+    The C oracle's indices for those columns are compared with the GPU's: the checker checking the timed run."""
+    import torch
     import oracle
     ncores = os.cpu_count() or 1
     nthreads = min(ncores, 16)
     torch.set_num_threads(nthreads)
-    shapes = []
-    seen = set()
-    for name, N, d, m in layers:
-        if (N, d, m) not in seen and (N, m) in ((512, 3072), (256, 7168), (128, 26624), (64, 93184)):
-            seen.add((N, d, m))
-            shapes.append((name, N, d, m))
+    picked, seen = [], set()
+    for name, W, A, X, step, m in data:
+        N = W.shape[0]
+        if (N, m) in ((512, 3072), (256, 7168), (128, 26624), (64, 93184)) and (N, m) not in seen:
+            seen.add((N, m))
+            picked.append((name, W, A, X, step, m))
     tot_w = tot_t = tot_w_c = tot_t_c = 0.0
-    sample = []
-    for name, N, d, m in shapes:
+    sample, mismatches, checked = [], 0, 0
+    for name, Wd, Ad, Xd, step, m in picked:
+        N, d = Wd.shape
         cap = min(d, 512)
-        W, A, X = bw.synthetic_layer(N, d, m, 4321, d_limit=cap)
-        step = bw.layer_step(W)
+        W, A, X = Wd[:, :cap].cpu().contiguous(), Ad[:, :cap].cpu().contiguous(), Xd[:, :cap].cpu().contiguous()
         Q = torch.zeros_like(W)
         U = torch.zeros(N, m)
         stept = torch.tensor(step)
         cols, t0 = 0, time.perf_counter()
-        while cols < cap and (cols < 8 or time.perf_counter() - t0 < budget_s / len(shapes)):
+        while cols < cap and (cols < 8 or time.perf_counter() - t0 < budget_s / len(picked)):
             oracle.torch_restatement_quantization(W[:, cols:cols + 4], Q[:, cols:cols + 4], U, A[:, cols:cols + 4],
                                                   X[:, cols:cols + 4], stept, 8)
             cols += 4
@@ -65,20 +127,26 @@ def cpu_baseline(layers, budget_s=20.0):
         tot_t += dt
         ccap = min(cap, 128)
         t0 = time.perf_counter()
-        oracle.quantization(W[:, :ccap].numpy(), A[:, :ccap].numpy(), X[:, :ccap].numpy(), step, 8, nthreads=nthreads)
+        Qc, idxc, Uc = oracle.quantization(W[:, :ccap].numpy(), A[:, :ccap].numpy(), X[:, :ccap].numpy(), step, 8, nthreads=nthreads)
         dtc = time.perf_counter() - t0
-        cap = ccap
-        tot_w_c += N * cap
+        tot_w_c += N * ccap
         tot_t_c += dtc
+        got = gpu_idx[name][:, :ccap].cpu().numpy().astype("int16")
+        bad = int((got != idxc).sum())
+        mismatches += bad
+        checked += N * ccap
         sample.append("%s first %d cols" % (name, cols))
-        log("cpu baseline %-16s N=%d m=%d: torch-op restatement %d cols %.2fs (%.4f Mw/s); C oracle %d cols %.2fs (%.4f Mw/s)"
-            % (name, N, m, cols, dt, N * cols / dt / 1e6, cap, dtc, N * cap / dtc / 1e6))
-    return {"value": round(tot_w / tot_t / 1e6, 5), "unit": "M weights/s", "cores": nthreads, "kind": "port",
+        log("cpu baseline %-16s N=%d m=%d: torch-op restatement %d cols %.2fs (%.4f Mw/s); C oracle %d cols %.2fs (%.4f Mw/s); "
+            "GPU idx vs oracle on those columns: %d mismatches" % (name, N, m, cols, dt, N * cols / dt / 1e6, ccap, dtc,
+                                                                  N * ccap / dtc / 1e6, bad))
+    base = {"value": round(tot_w / tot_t / 1e6, 5), "unit": "M weights/s", "cores": nthreads, "kind": "port",
             "sample": "torch-op restatement of step_algorithm.py:140-148 on " + "; ".join(sample),
             "host_cores": ncores, "c_oracle_value": round(tot_w_c / tot_t_c / 1e6, 5)}
+    return base, {"against": "CPU oracle, first 128 columns of %d layers" % len(picked), "weights": checked,
+                  "mismatches": mismatches}
 
 
-def kernel_name(desc):
+def kernel_name(desc, mode=0):
     """The template instantiation a plan description launches (quantized_neural_nets_amd/csrc launch_slab):
     the names rocprofv3 reports."""
     w = desc.split()
@@ -87,52 +155,58 @@ def kernel_name(desc):
     if w[0] == "resident":
         if int(kv.get("S", "0")) == 1:
             return "gpfq_wave_kernel<"
-        return "gpfq_resident_kernel<0, %d>" % (8 if waves <= 8 else 12 if waves <= 12 else 16)
+        return "gpfq_resident_kernel<%d, %d>" % (mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
-        if rt == 1:
-            return "gpfq_coop_kernel<1, 0, 12, 2>"
-        if rt == 2 or waves <= 8:
-            return "gpfq_coop_kernel<%d, 0, %d, 2>" % (rt, 8 if waves <= 8 else 12)
-        return "gpfq_coop_kernel<4, 0, 12, 1>"
+        return "gpfq_coop_kernel<%d, %d, %d" % (rt, mode, 8 if waves <= 8 else 12)
     return "gpfq_stream_kernel<%d, true" % rt
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (tools/pmc_traffic.py:
-    separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 FETCH_SIZE correction applied)."""
+def l2_column_bytes(desc, N, d, m_pad, groups=1):
+    """Bytes of activation columns the workgroups of a register-resident launch pull from L2 over the whole loop: every
+    workgroup (a tile of RT rows, or one of the C members of a tile) requests x_t and a_t for its own segments each
+    step -- 8 * m_pad bytes per row TILE per step, whatever C is.  None for the streaming kernels (HBM-bound)."""
+    w = desc.split()
+    if w[0] not in ("resident", "coop"):
+        return None
+    kv = dict(x.split("=") for x in w[1:] if "=" in x)
+    rt = int(kv["RT"])
+    Ng = N // groups
+    if w[0] == "resident" and int(kv.get("S", "0")) == 1:
+        tiles = groups * (-(-Ng // rt))           # wave kernel: one wave per RT rows
+    else:
+        tiles = groups * (-(-Ng // rt))
+    return tiles * d * 8 * m_pad
+
+
+def pmc_traffic(kernel, digest):
+    """HBM-side bytes per launch of `kernel` from a committed rocprofv3 PMC summary (tools/pmc_traffic.py: separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 FETCH_SIZE correction applied) -- but ONLY from a
+    summary stamped with the digest of the kernel sources this run was built from; otherwise null."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None, None
-    data = json.load(open(files[-1]))
-    for name, v in data.get("kernels", {}).items():
-        if kernel in name:
-            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
-    return None, None
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        data = json.load(open(path))
+        if data.get("source_sha256") != digest:
+            stale = stale or os.path.relpath(path, ROOT)
+            continue
+        for name, v in data.get("kernels", {}).items():
+            if kernel in name:
+                return v["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, ("no PMC summary for this kernel source (newest other: %s): collect with tools/pmc_traffic.py" % stale)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=None, help="calibration batch (default: the workload's named batch; 1024 for the headline)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--plan", type=int, default=0, help="0 auto, 1 stream, 2 resident (debug)")
-    ap.add_argument("--layers", default=None, help="substring filter on layer names (debug)")
-    ap.add_argument("--workload", default="r50_3x3", choices=sorted(bw.WORKLOADS),
-                    help="r50_3x3 = the headline config (sixteen 3x3 convs at batch 1024); secondary: r50_all_convs (all 53 "
-                         "conv layers), r18 (ResNet-18 at batch 256), vgg16 (VGG-16 at batch 512)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
-    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # before any GPU call: this process never initialises HIP
 
+    import torch
+    import bench_workload as bw
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     if args.share_gpu:
         local_rank = 0
@@ -140,6 +214,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from quantized_neural_nets_amd import StepAlgorithm, _lib, dist as qdist
+    from quantized_neural_nets_amd.step_algorithm import PreparedColumns
     import torch.distributed as td
     if world > 1:
         if args.backend == "nccl":
@@ -147,27 +222,37 @@ def main():
         else:
             td.init_process_group(args.backend)
         qdist.enable()
-    StepAlgorithm.plan = args.plan
     # host threads for the input generation: torchrun pins OMP_NUM_THREADS to 1 per rank; share the cores instead
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // max(world, 1))))
 
-    layer_fn, named_batch, workload_desc = bw.WORKLOADS[args.workload]
+    wl = bw.WORKLOADS[args.workload]
+    layer_fn, named_batch, workload_desc = wl[0], wl[1], wl[2]
+    qcfg = wl[3] if len(wl) > 3 else {}
+    bits, reg, lamb = qcfg.get("bits", 4), qcfg.get("reg"), qcfg.get("lamb", 0.1)
+    K = 2 ** (bits - 1)
+    mode = 1 if reg == "L1" else 2 if reg == "L0" else 0
     if args.batch is None:
         args.batch = named_batch
-    layers = layer_fn(args.batch)
+    layers = bw.normalize_layers(layer_fn(args.batch))          # (name, N, d_g, m, groups[, conv geometry])
     if args.layers:
         layers = [l for l in layers if args.layers in l[0]]
-    total_weights = sum(N * d for _, N, d, _ in layers)
-    alg_bytes = {name: bw.algorithmic_bytes(N, d, m) for name, N, d, m in layers}
+    total_weights = sum(l[1] * l[2] for l in layers)
+    alg_bytes = {l[0]: bw.algorithmic_bytes(l[1], l[2], l[3], l[4]) for l in layers}
 
     # ---- synthetic inputs, generated on the host (identical bits on every rank), resident in HBM
     t0 = time.perf_counter()
     data = []
-    for li, (name, N, d, m) in enumerate(layers):
-        W, A, X = bw.synthetic_layer(N, d, m, 1234 + li, first_layer=False)
-        step = bw.layer_step(W)
-        data.append((name, W.to(dev), A.to(dev), X.to(dev), step, m))
-        del W, A, X
+    for li, (name, N, dg, m, groups) in enumerate(l[:5] for l in layers):
+        if args.capture:
+            W, fmap_a, fmap_x, geom, sel = bw.synthetic_capture_layer(layers[li], args.batch, 1234 + li)
+            step = bw.layer_step(W, 1.16, K)
+            data.append((name, W.to(dev), (fmap_a.to(dev), fmap_x.to(dev), geom, sel.to(dev)), None, step, m))
+        else:
+            W, A, X = bw.synthetic_layer(N, groups * dg, m, 1234 + li, first_layer=False, rows_d=dg)
+            step = bw.layer_step(W, 1.16, K)
+            data.append((name, W.to(dev), A.to(dev), X.to(dev), step, m))
+            del A, X
+        del W
     torch.cuda.synchronize()
     if rank == 0:
         log("inputs: %d layers, %.3f M weights, generated in %.1fs" % (len(layers), total_weights / 1e6,
@@ -175,6 +260,10 @@ def main():
 
     events = []          # (layer name, tag, event) recorded by the hook inside the timed region
     cur = {"name": None, "on": False}
+    last_idx = {}
+    timeouts = []
+    groups_of = {l[0]: l[4] for l in layers}
+    plan = args.plan or None
 
     def hook(tag, shape):
         if cur["on"]:
@@ -182,13 +271,39 @@ def main():
             ev.record()
             events.append((cur["name"], tag, ev))
 
-    StepAlgorithm.event_hook = hook
+    def gather(fmap, geom, sel, m):
+        """the driver's fused capture (quantize_neural_net.py SaveInputConv2d): sampled patches -> (D, m_pad) columns"""
+        import ctypes
+        B, C, H, Wd = fmap.shape
+        kh, kw, ph, pw = geom
+        mp = _lib.lib.gpfq_padded_m(m)
+        T = torch.empty((C * kh * kw, mp), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.gpfq_gather_patches_f32(
+            ctypes.c_void_p(fmap.data_ptr()), B, C, H, Wd, kh, kw, ph, pw, 1, 1, ctypes.c_void_p(sel.data_ptr()), m,
+            ctypes.c_void_p(T.data_ptr()), mp, _lib.current_stream_ptr(dev)))
+        return PreparedColumns(T, m)
 
-    def one_step():
+    def run_layer(name, W, A, X, step, m, plan_, hook_):
+        if args.capture:
+            fa, fx_, geom, sel = A
+            if hook_:
+                hook_("prepare_begin", None)
+            A, X = gather(fa, geom, sel, m), gather(fx_, geom, sel, m)
+            r = StepAlgorithm._quantize_layer_ex(W, A, X, m, 1.16 / K, K, 1, reg, lamb, groups_of[name], False, dev,
+                                                 compute_errors=False, step_override=step, plan=plan_,
+                                                 event_hook=(lambda tag, s: hook_(tag, s) if tag != "prepare_begin" else None) if hook_ else None)
+        else:
+            r = StepAlgorithm._quantize_layer_ex(W, A, X, m, 1.16 / K, K, 1, reg, lamb, groups_of[name], False, dev,
+                                                 compute_errors=False, step_override=step, plan=plan_, event_hook=hook_)
+        return r
+
+    def one_step(keep=False):
         for name, W, A, X, step, m in data:
             cur["name"] = name
-            StepAlgorithm._quantize_layer_ex(W, A, X, m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev,
-                                             compute_errors=False, step_override=step)
+            r = run_layer(name, W, A, X, step, m, plan, hook)
+            timeouts.extend(r["timeouts"])
+            if keep:
+                last_idx[name] = r["idx"]
 
     def fence():
         torch.cuda.synchronize()
@@ -199,18 +314,37 @@ def main():
     for _ in range(args.warmup):
         one_step()
     fence()
+    del timeouts[:]
     cur["on"] = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    for s in range(args.steps):
+        one_step(keep=(s == args.steps - 1))
     fence()
     elapsed = time.perf_counter() - t0
     cur["on"] = False
-    _lib.check_status(dev)          # a cooperative kernel that gave up waiting for a peer invalidates the run
+    _lib.check_status(dev)
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- output check: the timed run's indices against a rerun on the streaming kernel family
+    output_check = None
+    if not args.no_output_check:
+        nbad = nchk = nlay = 0
+        for name, W, A, X, step, m in data:
+            if alg_bytes[name] > 300e9 and args.workload != "r50_3x3":
+                continue                                         # hundreds of ms per layer on the streaming plan: skip
+            auto = _lib.describe_plan(W.shape[0], W.shape[1], m, groups_of[name], 0)
+            alt = _lib.PLAN_STREAM_ROWS if auto.startswith("stream") else _lib.PLAN_STREAM
+            r = run_layer(name, W, A, X, step, m, alt, None)
+            torch.cuda.synchronize()
+            nbad += int((r["idx"] != last_idx[name]).sum())
+            nchk += r["idx"].numel()
+            nlay += 1
+        output_check = {"against": "rerun on the streaming kernel family", "layers": nlay, "weights": nchk, "mismatches": nbad}
+        if rank == 0:
+            log("output check: %d layers, %d weights, %d index mismatches vs the streaming rerun" % (nlay, nchk, nbad))
 
     # ---- per-launch durations of the loop kernel from the events recorded on the launch stream
     per_layer = {}
@@ -223,42 +357,79 @@ def main():
         rec["loop_ms"] += e1.elapsed_time(e2)
         rec["n"] += 1
     fam = {}
-    for name, N, d, m in layers:
+    table = []
+    prep_ms_total = loop_ms_total = 0.0
+    for name, N, dg, m, groups in (l[:5] for l in layers):
         rec = per_layer.get(name)
         if not rec:
             continue
         Nl = N
         if world > 1:
-            kind_, chunk = qdist.partition(N, 1, world)
-            a, b = qdist.local_range(kind_, chunk, N, 1, rank)
-            Nl = b - a
-        desc = _lib.describe_plan(max(Nl, 1), d, m)
-        kind = kernel_name(desc)
-        f = fam.setdefault(kind, {"ms": 0.0, "bytes": 0.0, "launches": 0})
+            kind_, chunk = qdist.partition(N, groups, world)
+            a, b = qdist.local_range(kind_, chunk, N, groups, rank)
+            Nl = (b - a) if kind_ == "rows" else (b - a) * (N // groups) if kind_ == "groups" else (b - a) * groups
+        gl = groups if world == 1 else max(1, min(groups, Nl))
+        desc = _lib.describe_plan(max(Nl, 1), dg, m, gl if Nl % gl == 0 else 1, args.plan)
+        kind = kernel_name(desc, mode)
+        mp = _lib.lib.gpfq_padded_m(m)
+        l2b = l2_column_bytes(desc, max(Nl, 1), dg, mp, gl if Nl % gl == 0 else 1)
+        ab = bw.algorithmic_bytes(Nl, dg, m, gl if Nl % gl == 0 else 1)
+        f = fam.setdefault(kind, {"ms": 0.0, "bytes": 0.0, "launches": 0, "l2": 0.0, "l2_known": True})
         f["ms"] += rec["loop_ms"]
-        f["bytes"] += bw.algorithmic_bytes(Nl, d, m) * rec["n"]
+        f["bytes"] += ab * rec["n"]
         f["launches"] += rec["n"]
+        if l2b is None:
+            f["l2_known"] = False
+        else:
+            f["l2"] += l2b * rec["n"]
+        lm, pm = rec["loop_ms"] / rec["n"], rec["prep_ms"] / rec["n"]
+        prep_ms_total += pm
+        loop_ms_total += lm
+        row = ("%-22s N=%4d d=%5d g=%4d m=%6d %-26s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg = %5.1f%% of 8 TB/s HBM%s)  prep %7.3f ms"
+               % (name, N, dg, groups, m, " ".join(desc.split()[:3]), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
+                  "" if l2b is None else "; %5.0f GB/s L2 columns = %4.1f%% of 34.5 TB/s" % (l2b / lm / 1e6, l2b / lm / 1e6 / L2_PEAK_GBPS * 100),
+                  pm))
+        table.append(row)
         if rank == 0:
-            lm, pm = rec["loop_ms"] / rec["n"], rec["prep_ms"] / rec["n"]
-            log("%-16s N=%4d d=%5d m=%6d %-24s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg, %5.1f%% of 8 TB/s)  prep %7.3f ms"
-                % (name, N, d, m, " ".join(desc.split()[:3]), lm, lm * 1e3 / d, bw.algorithmic_bytes(Nl, d, m) / lm / 1e6,
-                   bw.algorithmic_bytes(Nl, d, m) / lm / 1e6 / HBM_PEAK_GBPS * 100, pm))
+            log(row)
+    if rank == 0 and args.layer_table:
+        with open(args.layer_table, "w") as fh:
+            fh.write("\n".join(table) + "\n")
 
     if rank == 0:
         dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
-        roofline = None
+        roofline = roofline_l2 = None
         if dom:
             f = fam[dom]
             achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
-            traffic, tsrc = pmc_traffic(dom)
+            digest = _lib.kernel_source_digest()
+            traffic, tsrc = pmc_traffic(dom, digest)
+            resident = f["l2_known"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                         "traffic": traffic, "traffic_source": tsrc, "launches": f["launches"],
                         "avg_launch_ms": round(f["ms"] / f["launches"], 4),
                         "alg_bytes_per_launch": round(f["bytes"] / f["launches"]),
+                        "note": ("SURVEY 8(d) algorithmic bytes (8*N*m per step) over the measured launch time. The residual U "
+                                 "of this kernel is REGISTER-RESIDENT for the whole loop, so these bytes never reach HBM and "
+                                 "the fraction exceeds 1: HBM does not bind this kernel -- see roofline_l2 for the bound that does"
+                                 if resident else "residual streamed through HBM / Infinity Cache every step"),
+                        "kernel_source_sha256": digest,
                         "families": {k: {"ms_total": round(v["ms"], 3), "launches": v["launches"],
-                                         "achieved_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                                         "achieved_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                         "l2_column_GBps": round(v["l2"] / (v["ms"] * 1e-3) / 1e9, 1) if v["l2_known"] else None}
                                      for k, v in fam.items()}}
+            if resident:
+                l2a = f["l2"] / (f["ms"] * 1e-3) / 1e9
+                roofline_l2 = {"bound": "l2", "kernel": dom, "achieved": round(l2a, 1), "peak": L2_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(l2a / L2_PEAK_GBPS, 4),
+                               "column_bytes_per_launch": round(f["l2"] / f["launches"]),
+                               "definition": "activation-column bytes the workgroups request from L2: 8*m_pad per row tile "
+                                             "(RT rows share one request) per step, summed over the launch, / launch time; "
+                                             "peak = MI355X_MICROARCH.md L2 aggregate 34.5 TB/s",
+                               "whole_job_frac": round(sum(v["l2"] for v in fam.values() if v["l2_known"]) /
+                                                       (sum(v["ms"] for v in fam.values() if v["l2_known"]) * 1e-3) / 1e9 / L2_PEAK_GBPS, 4)}
+        cfg_desc = "%d-bit (K=%d)%s, scalar 1.16, retain_rate 0.25" % (bits, K, ", %s lamb %g" % (reg, lamb) if reg else "")
         out = {
             "metric": "M weights quantized/sec (GPFQ loop), %s, calib batch %d"
                       % ("ResNet-50 conv layers" if args.workload.startswith("r50") else workload_desc.split(" all")[0] + " layers", args.batch),
@@ -271,17 +442,28 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload_desc + ", calibration batch %d, 4-bit (K=8), scalar 1.16, "
-                                   "retain_rate 0.25" % args.batch,
+            "config": {"workload": workload_desc + ", calibration batch %d, %s" % (args.batch, cfg_desc),
                        "layers": len(layers), "weights": total_weights,
                        "algorithmic_bytes": sum(alg_bytes.values()),
+                       "column_prep": "fused patch gather from feature maps (driver path)" if args.capture else "transpose of (m, d) matrices",
                        "parallelism": "neuron-shard x%d + all_gather(int8 idx)" % world if world > 1 else "single GPU"},
             "roofline_whole_job_frac": round(sum(alg_bytes.values()) * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS / max(world, 1), 4),
+            "prep_ms_per_step": round(prep_ms_total, 3), "loop_ms_per_step": round(loop_ms_total, 3),
+            "cooperative_timeouts": len(timeouts),
             "roofline": roofline,
+            "roofline_l2": roofline_l2,
+            "output_check": output_check,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "r50_3x3":
-            out["cpu_baseline"] = cpu_baseline(layers)
+        failed = bool(output_check and output_check["mismatches"])
+        if world == 1 and not args.no_cpu_baseline and args.workload == "r50_3x3" and not args.capture and not args.layers:
+            out["cpu_baseline"], out["oracle_check"] = cpu_baseline(data, last_idx)
+            failed = failed or bool(out["oracle_check"]["mismatches"])
         print(json.dumps(out), flush=True)
+        if failed:
+            log("bench.py: OUTPUT CHECK FAILED")
+            if world > 1:
+                td.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         td.destroy_process_group()
 

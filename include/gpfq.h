@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GPFQ_ABI_VERSION 1
+#define GPFQ_ABI_VERSION 2   /* 2: usq_seg outputs, GPFQ_PLAN_STREAM_ROWS, gpfq_last_launch_used_exchange */
 
 /* quantizer selection, step_algorithm.py:198-208 */
 enum {
@@ -39,7 +39,9 @@ enum {
     GPFQ_PLAN_AUTO = 0,
     GPFQ_PLAN_STREAM = 1,     /* residual U streamed through HBM/L2 every step (any size)        */
     GPFQ_PLAN_RESIDENT = 2,   /* residual U resident in registers for the whole column loop      */
-    GPFQ_PLAN_COOP = 3        /* resident, each row split by columns over C co-operating workgroups */
+    GPFQ_PLAN_COOP = 3,       /* resident, each row split by columns over C co-operating workgroups */
+    GPFQ_PLAN_STREAM_ROWS = 4 /* streamed, whole rows per workgroup: never waits for another workgroup (the
+                                 fallback after GPFQ_ERR_TIMEOUT; slower than the other plans on few long rows) */
 };
 
 /* error codes */
@@ -79,6 +81,14 @@ size_t gpfq_scratch_bytes(void);
 int gpfq_read_status(void* scratch, int* status_host4, void* stream);
 
 /*
+ * 1 if the last loop launch made from this host thread used a plan whose workgroups wait for each other (the
+ * cooperative plan, or the streaming plan with a row's columns split over workgroups), i.e. if its outputs are
+ * valid only once gpfq_read_status has returned 0; 0 for the plans that cannot time out.  Lets a caller skip the
+ * synchronising status read after the other launches.
+ */
+int gpfq_last_launch_used_exchange(void);
+
+/*
  * Column preparation: AT[t][k] = A[k][t], XT[t][k] = X[k][t] for k < m, zero for m <= k < m_pad, and
  * nrm2[t] = ||X[:, t]||_2 ** 2 exactly as step_algorithm.py:142 spells it (sqrt of the sum of squares,
  * squared) with the canonical reduction order.  Replaces the strided column reads of
@@ -101,14 +111,17 @@ int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_
  *   index encoding: msq / soft / stochastic -> k in [-K, K], Q = sign(k)*step*|k|;
  *                   hard -> 0 or +-(k+1), k in [0, K], Q = +-(lamb + step*k)
  *   seed, row_id0: key of the counter-based generator of GPFQ_MODE_STOCHASTIC (row_id0 = global index of row 0)
+ *   usq_seg [N][m_pad/1024]  optional (may be NULL): sum of squares of every 1024-element segment of the FINAL
+ *                   residual, accumulated in the kernel's last step -- the caller sums a row's segments to get
+ *                   ||U[i,:]||^2 for the error metrics of step_algorithm.py:216-219 / :239-243 without a pass over U
  *   plan: GPFQ_PLAN_*       scratch: gpfq_scratch_bytes() bytes or NULL (then the cooperative plan is not used)
  */
 int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, float* U, int64_t ldu,
                           int u_has_init, const float* AT, const float* XT, const float* nrm2,
                           int64_t N, int64_t d, int64_t m, int64_t m_pad,
                           float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
-                          void* idx, int64_t ldi, int idx_bytes, int plan, void* scratch, size_t scratch_bytes,
-                          void* stream);
+                          void* idx, int64_t ldi, int idx_bytes, float* usq_seg, int plan, void* scratch,
+                          size_t scratch_bytes, void* stream);
 
 /*
  * One whole layer (all groups in one launch) -- the native part of
@@ -125,7 +138,7 @@ int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, fl
 int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const float* X, int64_t ldx,
                             int64_t N, int64_t d_g, int64_t m, int groups,
                             float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
-                            float* Q, void* idx, int idx_bytes, float* U,
+                            float* Q, void* idx, int idx_bytes, float* U, float* usq_seg,
                             void* workspace, size_t workspace_bytes, int plan, void* stream);
 
 /*
@@ -136,8 +149,8 @@ int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const f
 int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const float* AT, const float* XT,
                                       const float* nrm2, int64_t N, int64_t d_g, int64_t m, int64_t m_pad,
                                       int groups, float step, int K, int mode, float lamb, uint64_t seed,
-                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* scratch,
-                                      size_t scratch_bytes, void* stream);
+                                      uint64_t row_id0, void* idx, int idx_bytes, float* usq_seg, int plan,
+                                      void* scratch, size_t scratch_bytes, void* stream);
 
 /*
  * Elementwise quantizer on a device vector (the four quantizers as standalone ops, for known-answer

@@ -14,13 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPFQ_LIB_OVERRIDE") or os.path.join(_HERE, "libgpfq_hip.so")   # override: diagnostic builds
 
 MODE_MSQ, MODE_SOFT, MODE_HARD, MODE_STOCHASTIC = 0, 1, 2, 3
-PLAN_AUTO, PLAN_STREAM, PLAN_RESIDENT, PLAN_COOP = 0, 1, 2, 3
+PLAN_AUTO, PLAN_STREAM, PLAN_RESIDENT, PLAN_COOP, PLAN_STREAM_ROWS = 0, 1, 2, 3, 4
 
 EXPORTS = [
     "gpfq_abi_version", "gpfq_last_error", "gpfq_padded_m", "gpfq_workspace_bytes",
     "gpfq_prepare_columns_f32", "gpfq_quantization_f32", "gpfq_quantize_layer_f32", "gpfq_quantizer_f32",
     "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32", "gpfq_scratch_bytes",
-    "gpfq_read_status", "gpfq_column_norms_f32", "gpfq_gather_patches_f32",
+    "gpfq_read_status", "gpfq_column_norms_f32", "gpfq_gather_patches_f32", "gpfq_last_launch_used_exchange",
 ]
 
 
@@ -56,13 +56,14 @@ def _load():
     lib.gpfq_prepare_columns_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, vp, vp, i64, vp]
     lib.gpfq_quantization_f32.restype = i32
     lib.gpfq_quantization_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, i64, i64, i64,
-                                          f32, i32, i32, f32, u64, u64, vp, i64, i32, i32, vp, sz, vp]
+                                          f32, i32, i32, f32, u64, u64, vp, i64, i32, vp, i32, vp, sz, vp]
     lib.gpfq_quantize_layer_f32.restype = i32
     lib.gpfq_quantize_layer_f32.argtypes = [vp, vp, i64, vp, i64, i64, i64, i64, i32, f32, i32, i32, f32, u64, u64,
-                                            vp, vp, i32, vp, vp, sz, i32, vp]
+                                            vp, vp, i32, vp, vp, vp, sz, i32, vp]
     lib.gpfq_quantize_groups_prepared_f32.restype = i32
     lib.gpfq_quantize_groups_prepared_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, i32, i32,
-                                                      f32, u64, u64, vp, i32, i32, vp, sz, vp]
+                                                      f32, u64, u64, vp, i32, vp, i32, vp, sz, vp]
+    lib.gpfq_last_launch_used_exchange.restype = i32
     lib.gpfq_column_norms_f32.restype = i32
     lib.gpfq_column_norms_f32.argtypes = [vp, i64, i64, i64, vp, vp]
     lib.gpfq_gather_patches_f32.restype = i32
@@ -76,12 +77,15 @@ def _load():
     lib.gpfq_row_absmax_f32.argtypes = [vp, i64, i64, i64, vp, vp]
     lib.gpfq_describe_plan.restype = i32
     lib.gpfq_describe_plan.argtypes = [i64, i64, i64, i32, i32, c.c_char_p, sz]
-    if lib.gpfq_abi_version() != 1:
+    if lib.gpfq_abi_version() != 2:
         raise ImportError("libgpfq_hip.so ABI version mismatch")
     return lib
 
 
 lib = _load()
+
+
+from ._digest import kernel_source_digest  # noqa: E402,F401
 
 
 def check(rc):
@@ -104,20 +108,37 @@ _scratch = {}
 
 
 def scratch(device):
-    """Per-device scratch area of the cooperative plan (allocated and zeroed once)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """Scratch area of the cooperative plans (exchange granules + status words), one per (device, stream): launches on
+    one stream are serialised by the stream, and two streams never share granules.  Allocated and zeroed once."""
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream)
     buf = _scratch.get(key)
     if buf is None:
-        buf = torch.zeros((lib.gpfq_scratch_bytes(),), dtype=torch.uint8, device=torch.device("cuda", key))
+        buf = torch.zeros((lib.gpfq_scratch_bytes(),), dtype=torch.uint8, device=torch.device("cuda", index))
         _scratch[key] = buf
     return buf
 
 
-def check_status(device):
-    """Synchronise and raise if a cooperative kernel reported a timeout since the last check."""
+def _read_status(device):
     buf = scratch(device)
     st = (ctypes.c_int * 4)()
     rc = lib.gpfq_read_status(ctypes.c_void_p(buf.data_ptr()), st, current_stream_ptr(buf.device))
+    return rc, st
+
+
+def status_ok(device):
+    """Synchronise the current stream and report whether every cooperative launch on it since the last read ran to
+    completion (False: one gave up waiting for a peer workgroup; its outputs are invalid).  Clears the status."""
+    rc, st = _read_status(device)
+    if rc not in (0, -5):
+        raise GpfqError("gpfq error %d: %s" % (rc, lib.gpfq_last_error().decode()))
+    return rc == 0
+
+
+def check_status(device):
+    """Synchronise and raise if a cooperative kernel reported a timeout since the last check."""
+    rc, st = _read_status(device)
     if rc != 0:
         raise GpfqError("gpfq error %d: %s (column %d, row tile %d, member %d)" % (
             rc, lib.gpfq_last_error().decode(), st[1], st[2], st[3]))

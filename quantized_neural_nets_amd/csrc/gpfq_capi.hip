@@ -24,6 +24,7 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local int g_used_exchange = 0;    // did this thread's last loop launch wait on other workgroups (status word matters)?
 
 int fail(int code, const std::string& msg)
 {
@@ -180,7 +181,12 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     pl.C = 1; pl.tiles = 0;
     if (m_pad / gpfq::kSeg > 1024) return fail(GPFQ_ERR_UNSUPPORTED, "m > 1048576 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
-    if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_COOP) return fail(GPFQ_ERR_ARG, "unknown plan id");
+    if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_STREAM_ROWS) return fail(GPFQ_ERR_ARG, "unknown plan id");
+    if (requested == GPFQ_PLAN_STREAM_ROWS) {            // whole rows per workgroup: never waits for another workgroup
+        choose_stream(Ng, pl.S, groups, false, &pl);
+        *out = pl;
+        return GPFQ_OK;
+    }
     if (requested == GPFQ_PLAN_RESIDENT && pl.S > kMaxResidentSegments)
         return fail(GPFQ_ERR_UNSUPPORTED, "resident plan needs m_pad <= 16384");
     const int cus = device_cu_count();
@@ -261,7 +267,7 @@ int launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool ve
 gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, bool vec, void* scratch)
 {
     gpfq::SlabParams sp;
-    sp.W = p.W; sp.Q = p.Q; sp.U = p.U; sp.idx = p.idx; sp.AT = p.AT; sp.XT = p.XT; sp.nrm2 = p.nrm2;
+    sp.W = p.W; sp.Q = p.Q; sp.U = p.U; sp.idx = p.idx; sp.AT = p.AT; sp.XT = p.XT; sp.nrm2 = p.nrm2; sp.usq = p.usq;
     sp.xbuf = reinterpret_cast<unsigned long long*>(scratch);
     sp.status = scratch ? reinterpret_cast<int*>(static_cast<char*>(scratch) + kScratchStatusOffset) : nullptr;
     sp.ldw = p.ldw; sp.ldq = p.ldq; sp.ldu = p.ldu; sp.ldi = p.ldi; sp.m = p.m; sp.m_pad = p.m_pad;
@@ -400,9 +406,10 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     Plan pl;
     // the register-resident plans start from U = 0; a caller-provided initial residual (the in-place
     // _quantization surface) streams through memory
+    g_used_exchange = 0;
     if (p.u_has_init && plan == GPFQ_PLAN_AUTO) plan = GPFQ_PLAN_STREAM;
-    if (p.u_has_init && plan != GPFQ_PLAN_STREAM)
-        return fail(GPFQ_ERR_UNSUPPORTED, "an initial residual needs the streaming plan");
+    if (p.u_has_init && plan != GPFQ_PLAN_STREAM && plan != GPFQ_PLAN_STREAM_ROWS)
+        return fail(GPFQ_ERR_UNSUPPORTED, "an initial residual needs a streaming plan");
     int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, &pl);
     if (rc) return rc;
     if (groups > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "groups > 65535");
@@ -410,6 +417,7 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     const bool vec = ((p.ldu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.U) & 15) == 0);
     if (pl.kind == GPFQ_PLAN_COOP) {
         rc = launch_slab(pl, p, groups, vec, scratch, st);
+        if (rc == GPFQ_OK) g_used_exchange = 1;
         if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
         rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, &pl);   // does not fit: stream instead
         if (rc) return rc;
@@ -421,6 +429,7 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
         case 2: rc = launch_stream<2>(pl, p, groups, vec, scratch, st); break;
         default: rc = launch_stream<1>(pl, p, groups, vec, scratch, st); break;
         }
+        if (rc == GPFQ_OK && pl.C > 1) g_used_exchange = 1;
         if (rc != GPFQ_ERR_UNSUPPORTED || pl.C <= 1) return rc;
         choose_stream(p.Ng, pl.S, groups, false, &pl);          // cooperative grid did not fit: whole rows
     }
@@ -444,6 +453,8 @@ int check_mode(int mode, int K, int idx_bytes, const void* idx)
 extern "C" {
 
 int gpfq_abi_version(void) { return GPFQ_ABI_VERSION; }
+
+int gpfq_last_launch_used_exchange(void) { return g_used_exchange; }
 
 const char* gpfq_last_error(void) { return g_err.c_str(); }
 
@@ -515,8 +526,8 @@ int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, fl
                           int u_has_init, const float* AT, const float* XT, const float* nrm2,
                           int64_t N, int64_t d, int64_t m, int64_t m_pad,
                           float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
-                          void* idx, int64_t ldi, int idx_bytes, int plan, void* scratch, size_t scratch_bytes,
-                          void* stream)
+                          void* idx, int64_t ldi, int idx_bytes, float* usq_seg, int plan, void* scratch,
+                          size_t scratch_bytes, void* stream)
 {
     if (!W || !Q || !U || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
     if (N < 0 || d < 0 || m < 0 || ldw < d || ldq < d || ldu < m || (idx && ldi < d))
@@ -528,15 +539,15 @@ int gpfq_quantization_f32(const float* W, int64_t ldw, float* Q, int64_t ldq, fl
     p.W = W; p.ldw = ldw; p.Q = Q; p.ldq = ldq; p.U = U; p.ldu = ldu; p.u_has_init = u_has_init;
     p.AT = AT; p.XT = XT; p.nrm2 = nrm2; p.Ng = N; p.d = d; p.m = m; p.m_pad = m_pad; p.S = 0;
     p.qc.step = step; p.qc.Kf = (float)K; p.qc.lamb = lamb; p.qc.mode = mode; p.qc.seed = seed;
-    p.row_id0 = row_id0; p.idx = idx; p.ldi = ldi; p.idx_bytes = idx_bytes;
+    p.row_id0 = row_id0; p.idx = idx; p.ldi = ldi; p.idx_bytes = idx_bytes; p.usq = usq_seg;
     return run_loop(p, 1, plan, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const float* AT, const float* XT,
                                       const float* nrm2, int64_t N, int64_t d_g, int64_t m, int64_t m_pad,
                                       int groups, float step, int K, int mode, float lamb, uint64_t seed,
-                                      uint64_t row_id0, void* idx, int idx_bytes, int plan, void* scratch,
-                                      size_t scratch_bytes, void* stream)
+                                      uint64_t row_id0, void* idx, int idx_bytes, float* usq_seg, int plan,
+                                      void* scratch, size_t scratch_bytes, void* stream)
 {
     if (!W || !Q || !U || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
     if (groups < 1 || N < 0 || d_g < 0 || m < 0) return fail(GPFQ_ERR_ARG, "bad shape");
@@ -548,14 +559,14 @@ int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const 
     p.W = W; p.ldw = d_g; p.Q = Q; p.ldq = d_g; p.U = U; p.ldu = m; p.u_has_init = 0;
     p.AT = AT; p.XT = XT; p.nrm2 = nrm2; p.Ng = N / groups; p.d = d_g; p.m = m; p.m_pad = m_pad; p.S = 0;
     p.qc.step = step; p.qc.Kf = (float)K; p.qc.lamb = lamb; p.qc.mode = mode; p.qc.seed = seed;
-    p.row_id0 = row_id0; p.idx = idx; p.ldi = d_g; p.idx_bytes = idx_bytes;
+    p.row_id0 = row_id0; p.idx = idx; p.ldi = d_g; p.idx_bytes = idx_bytes; p.usq = usq_seg;
     return run_loop(p, groups, plan, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
 int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const float* X, int64_t ldx,
                             int64_t N, int64_t d_g, int64_t m, int groups,
                             float step, int K, int mode, float lamb, uint64_t seed, uint64_t row_id0,
-                            float* Q, void* idx, int idx_bytes, float* U,
+                            float* Q, void* idx, int idx_bytes, float* U, float* usq_seg,
                             void* workspace, size_t workspace_bytes, int plan, void* stream)
 {
     if (!W || !A || !X || !Q || !U || !workspace) return fail(GPFQ_ERR_ARG, "null pointer");
@@ -577,7 +588,7 @@ int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const f
     int rc = gpfq_prepare_columns_f32(A, lda, X, ldx, m, D, AT, XT, nrm2, mp, stream);
     if (rc) return rc;
     return gpfq_quantize_groups_prepared_f32(W, Q, U, AT, XT, nrm2, N, d_g, m, mp, groups, step, K, mode, lamb, seed,
-                                             row_id0, idx, idx_bytes, plan, ws, kScratchBytes, stream);
+                                             row_id0, idx, idx_bytes, usq_seg, plan, ws, kScratchBytes, stream);
 }
 
 int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, float lamb,

@@ -20,6 +20,7 @@ struct LoopParams {
     QuantCfg qc;
     uint64_t row_id0;
     void* idx; int64_t ldi; int idx_bytes;
+    float* usq;        // optional [rows][S]: per-segment sums of squares of the final residual (error-metric epilogue)
 };
 
 __device__ __forceinline__ void store_q(const LoopParams& p, int64_t grow, int64_t t, float q, int id)
@@ -85,6 +86,7 @@ __device__ __forceinline__ void store_u16(const float (&u)[16], float* __restric
 struct SlabParams {
     const float* W; float* Q; float* U; void* idx;
     const float* AT; const float* XT; const float* nrm2;
+    float* usq;
     unsigned long long* xbuf; int* status;
     int64_t ldw, ldq, ldu, ldi, m, m_pad;
     int Ng, d, S, C, tiles, idx_bytes, vec;
@@ -192,10 +194,22 @@ __device__ __forceinline__ void reducer_section(const SlabParams& p, const float
     }
 }
 
+// Sum of squares of one canonical segment of the final residual (lane chain from +0.0f, then the lane tree): the
+// in-kernel part of the error metrics ||U||_F and ||U^T||_col (step_algorithm.py:216-219, :239-243), so that no pass
+// over U is needed afterwards.  Wave-uniform call (EXEC full); lane 63 stores.
+__device__ __forceinline__ void store_segment_sumsq(float* usq, int64_t slot, const float (&u)[16], int lane)
+{
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc = __builtin_fmaf(u[e], u[e], acc);
+    const float sg = wave_tree64_lane63(acc);
+    if (lane == 63) usq[slot] = sg;
+}
+
 // Shared tail of the register-resident kernels: the pending subtraction of the last step, then the residual leaves the registers (step_algorithm.py:148).
 template <int RT>
 __device__ __forceinline__ void finish_rows(const SlabParams& p, float (&u)[RT][16], const float (&qprev)[RT], const Col16& xlast,
-                                            int row0, int64_t grow0, int64_t kbase)
+                                            int row0, int64_t grow0, int64_t kbase, int seg, int lane)
 {
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
@@ -208,6 +222,7 @@ __device__ __forceinline__ void finish_rows(const SlabParams& p, float (&u)[RT][
             float* Urow = p.U + (grow0 + r) * p.ldu;
             if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
             else store_u16<false>(u[r], Urow, kbase, p.m);
+            if (p.usq) store_segment_sumsq(p.usq, (grow0 + r) * p.S + seg, u[r], lane);
         }
     }
 }
@@ -431,9 +446,9 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
     }
 #endif
     if (dead || !active) return;
-    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row0, grow0, kbase);
-    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row0, grow0, kbase);
-    else finish_rows<RT>(p, u, qprev, X2, row0, grow0, kbase);
+    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row0, grow0, kbase, myseg, lane);
+    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row0, grow0, kbase, myseg, lane);
+    else finish_rows<RT>(p, u, qprev, X2, row0, grow0, kbase, myseg, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -561,9 +576,9 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
     wait_landed<0>(X0, X1);
     wait_landed<0>(X2, A0);
     wait_landed<0>(A1);
-    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row, grow, kbase);
-    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row, grow, kbase);
-    else finish_rows<RT>(p, u, qprev, X2, row, grow, kbase);
+    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row, grow, kbase, wave, lane);
+    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row, grow, kbase, wave, lane);
+    else finish_rows<RT>(p, u, qprev, X2, row, grow, kbase, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -690,6 +705,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
                 float* Urow = p.U + (grow0 + r) * p.ldu;
                 if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
                 else store_u16<false>(u[r], Urow, kbase, p.m);
+                if (p.usq) store_segment_sumsq(p.usq, grow0 + r, u[r], lane);      // one-segment rows: S == 1
             }
         }
     };
@@ -796,6 +812,7 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCo
                     if (lane == 63) seg[r * n_max + (s - seg_lo)] = sg;
                 }
                 if (valid[r] || RT == 1) store_u16<VEC>(u[r], p.U + grow[r] * p.ldu, kbase, p.m);
+                if (last && p.usq && valid[r]) store_segment_sumsq(p.usq, grow[r] * S + s, u[r], lane);
             }
         }
         if (last) break;

@@ -106,8 +106,10 @@ def _col_slice(M, lo, hi):
 
 def quantize_sharded(ctx, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb, idx_dtype, run_rows):
     """Quantize this rank's neurons and gather the indices of all ranks.
-    run_rows(W_loc, groups_loc, A_loc, lda, X_loc, ldx, row_id0) -> (Q_loc, idx_loc, U_loc).
-    Returns (Q (N, dg), idx (N, dg), U_loc, rows) with rows = the global row numbers of U_loc."""
+    run_rows(W_loc, groups_loc, A_loc, lda, X_loc, ldx, row_id0) -> (Q_loc, idx_loc, U_loc, usq_seg_loc); row_id0
+    is the global number of local row 0: the stochastic quantizer's Philox key is (seed, global row, column), so
+    every launch covers ONE contiguous block of global rows.
+    Returns (Q (N, dg), idx (N, dg), U_loc, usq_seg_loc, rows) with rows = the global row numbers of U_loc."""
     N = W.shape[0]
     Ng = N // groups
     kind, chunk = partition(N, groups, ctx.world)
@@ -115,19 +117,25 @@ def quantize_sharded(ctx, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb, id
     dev = W.device
     if kind == "rows":
         rows = torch.arange(a, b, device=dev)
-        _, idx_loc, U_loc = run_rows(W[a:b], 1, A, lda, X, ldx, a)
+        _, idx_loc, U_loc, usq_loc = run_rows(W[a:b], 1, A, lda, X, ldx, a)
         gathered = _all_gather_rows(ctx, idx_loc, chunk)[:N]
     elif kind == "groups":
         rows = torch.arange(a * Ng, b * Ng, device=dev)
         A_loc = _col_slice(A, a * dg, max(b, a) * dg if b > a else a * dg)
         X_loc = _col_slice(X, a * dg, max(b, a) * dg if b > a else a * dg)
-        _, idx_loc, U_loc = run_rows(W[a * Ng:b * Ng], max(b - a, 1), A_loc, lda, X_loc, ldx, a * Ng)
+        _, idx_loc, U_loc, usq_loc = run_rows(W[a * Ng:b * Ng], max(b - a, 1), A_loc, lda, X_loc, ldx, a * Ng)
         gathered = _all_gather_rows(ctx, idx_loc, chunk * Ng)[:N]
     else:
         nl = b - a
         rows = (torch.arange(groups, device=dev)[:, None] * Ng + torch.arange(a, b, device=dev)[None, :]).reshape(-1)
-        W_loc = W.view(groups, Ng, dg)[:, a:b].reshape(groups * nl, dg).contiguous()
-        _, idx_loc, U_loc = run_rows(W_loc, groups, A, lda, X, ldx, 0)
+        # one launch per group (1 < groups < world <= 8: a handful): rows [a, b) of group g are the contiguous global
+        # rows g*Ng + a ..., which keeps the Philox keys of the stochastic quantizer equal to the single-GPU ones
+        W3 = W.view(groups, Ng, dg)
+        parts = [run_rows(W3[g, a:b].contiguous(), 1, _col_slice(A, g * dg, (g + 1) * dg), lda,
+                          _col_slice(X, g * dg, (g + 1) * dg), ldx, g * Ng + a) for g in range(groups)]
+        idx_loc = torch.cat([p[1] for p in parts], 0)
+        U_loc = torch.cat([p[2] for p in parts], 0)
+        usq_loc = torch.cat([p[3] for p in parts], 0)
         blk = torch.zeros((groups, chunk, dg), dtype=idx_loc.dtype, device=dev)
         blk[:, :nl] = idx_loc.view(groups, nl, dg)
         g = _all_gather_rows(ctx, blk.view(groups * chunk, dg), groups * chunk)
@@ -135,11 +143,12 @@ def quantize_sharded(ctx, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb, id
         gathered = g[:, :Ng].reshape(N, dg)
     gathered = gathered.contiguous()
     Q = rebuild_q(gathered, step, K, mode, lamb)
-    return Q, gathered, U_loc, rows
+    return Q, gathered, U_loc, usq_loc, rows
 
 
-def sharded_error_metrics(ctx, W, A, U_loc, groups, rows):
-    """step_algorithm.py:216-219 / :239-243 from per-rank partial sums of squares."""
+def sharded_error_metrics(ctx, W, A, usq_loc, groups, rows, U_loc=None):
+    """step_algorithm.py:216-219 / :239-243 from per-rank partial sums of squares.  usq_loc: ||U[i, :]||^2 of the
+    local rows (float64, from the loop kernel's epilogue); U_loc is only needed for gather_residual."""
     if hasattr(A, "matrix"):
         A = A.matrix()
     N, dg = W.shape
@@ -148,7 +157,7 @@ def sharded_error_metrics(ctx, W, A, U_loc, groups, rows):
     usq = torch.zeros((N,), dtype=torch.float32, device=dev)
     asq = torch.zeros((N,), dtype=torch.float32, device=dev)
     if rows.numel() > 0:
-        usq[rows] = (U_loc.double() ** 2).sum(1).float()
+        usq[rows] = usq_loc.float()
         W_loc = W[rows]
         if groups == 1:
             AW = A @ W_loc.T                                           # (m, n_loc)

@@ -72,6 +72,8 @@ class QuantizeNeuralNet:
         extract_layers(self.analog_network, self.analog_network_layers)
         self.quantized_network_layers = []
         extract_layers(self.quantized_network, self.quantized_network_layers)
+        self.plan = None            # kernel family for every layer (GPFQ_PLAN_*; None = auto) -- extra
+        self.stochastic_seed_base = 0   # layer i of this run draws Philox streams keyed by base + i -- extra
         self.layer_reports = []     # per-layer dicts (index, errors, step) -- extra, not in the reference
         self.layer_indices = []     # per-layer alphabet indices + step, what packed.save() writes -- extra
 
@@ -103,10 +105,15 @@ class QuantizeNeuralNet:
             else:
                 raise TypeError(f'The layer type {type(analog_layer)} is not currently supported')
 
-            Q, quantize_error, relative_quantize_error, quantize_adder, relative_adder = \
-                StepAlgorithm._quantize_layer(W, analog_in, quantized_in, analog_in.shape[0], step_size, K, pct,
-                                              self.reg, self.lamb, groups, self.stochastic_quantization,
-                                              self.device)
+            # the native counterpart of StepAlgorithm._quantize_layer (:150, :180); its result dict also carries the
+            # alphabet indices and the step, so nothing travels through class state and two quantizers can interleave
+            print(f'The number of groups: {groups}\n')
+            res = StepAlgorithm._quantize_layer_ex(W, analog_in, quantized_in, analog_in.shape[0], step_size, K, pct,
+                                                   self.reg, self.lamb, groups, self.stochastic_quantization,
+                                                   self.device, plan=self.plan,
+                                                   seed=self.stochastic_seed_base + done)
+            Q, quantize_error, relative_quantize_error = res["Q"], res["quantize_error"], res["relative_quantize_error"]
+            quantize_adder, relative_adder = res["quantize_adder"], res["relative_adder"]
             Q = Q.float() if W_shape is None else Q.reshape(W_shape).float()
             self.quantized_network_layers[layer_idx].weight.data = Q
 
@@ -114,11 +121,9 @@ class QuantizeNeuralNet:
             print(f'The relative quantization error of layer {layer_idx} is {relative_quantize_error.cpu().numpy()}.\n')
             self.layer_reports.append(dict(layer=layer_idx, quantize_error=float(quantize_error),
                                            relative_quantize_error=float(relative_quantize_error)))
-            last = StepAlgorithm.last_result
-            if last is not None and last.get("idx") is not None:
-                mode = 1 if self.reg == 'L1' else 2 if self.reg == 'L0' else 3 if self.stochastic_quantization else 0
-                self.layer_indices.append(dict(layer=layer_idx, idx=last["idx"].detach().cpu(), step=float(last["step"]),
-                                               K=int(K), mode=mode, lamb=float(self.lamb if self.lamb is not None else 0.0)))
+            mode = 1 if self.reg == 'L1' else 2 if self.reg == 'L0' else 3 if self.stochastic_quantization else 0
+            self.layer_indices.append(dict(layer=layer_idx, idx=res["idx"].detach().cpu(), step=float(res["step"]),
+                                           K=int(K), mode=mode, lamb=float(self.lamb if self.lamb is not None else 0.0)))
             if LAYER_LOGGING:
                 self._log_layer(layer_idx, W, Q, quantize_adder, relative_adder)
 

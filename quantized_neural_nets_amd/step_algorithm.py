@@ -85,15 +85,30 @@ def _elementwise(mode, step_size, x, boundary_idx, lamb, uniform=None):
     return out.view(x.shape)
 
 
-class StepAlgorithm:
+class _SeedCounter:
+    """Default seeds for the stochastic quantizer when the caller passes none (the reference's 12-argument
+    surface has no seed argument): one process-wide counter, so that successive layers draw independent streams.
+    Callers that need reproducibility or re-entrancy (QuantizeNeuralNet does) pass `seed=` explicitly."""
 
-    # seed of the counter-based generator used by the stochastic quantizer inside the loop kernels;
-    # advanced by every stochastic layer so that layers draw independent streams.
-    stochastic_seed = 0
-    # kernel family override for experiments / tests (see include/gpfq.h GPFQ_PLAN_*)
-    plan = _lib.PLAN_AUTO
-    # optional callable(tag, shape) invoked around the column preparation and the loop kernel (bench.py)
-    event_hook = None
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._next = 0
+
+    def take(self):
+        with self._lock:
+            v = self._next
+            self._next += 1
+            return v
+
+
+_default_seeds = _SeedCounter()
+
+
+class StepAlgorithm:
+    # There is NO mutable class state: the kernel family, the stochastic seed and the profiling hook are per-call
+    # arguments of _quantize_layer_ex / _quantization (plan=, seed=, event_hook=), and results are returned, never
+    # parked on the class.
 
     def _stochastic_msq(step_size, x, boundary_idx, lamb):
         '''Stochastic rounding to the alphabet, clipped to boundary_idx (step_algorithm.py:7-35).
@@ -116,12 +131,13 @@ class StepAlgorithm:
         return _elementwise(_lib.MODE_SOFT, step_size, x, boundary_idx, lamb)
 
     def _quantization(W, Q, U, analog_layer_input, quantized_layer_input, quantizer,
-                      step_size, boundary_idx, lamb):
+                      step_size, boundary_idx, lamb, plan=None, seed=None):
         '''The GPFQ loop over the columns of one group, in place on Q and U (step_algorithm.py:107-148).
 
         W, Q : (N, d) weights / quantized weights        U : (N, m) residual, read and updated
         analog_layer_input, quantized_layer_input : (m, d), may be strided views (:236)
         quantizer : one of the four StepAlgorithm quantizers (selects the fused epilogue)
+        plan : kernel family (include/gpfq.h GPFQ_PLAN_*; None = auto)   seed : stochastic quantizer's Philox key
         '''
         mode = _MODE_BY_NAME.get(getattr(quantizer, "__name__", None))
         if mode is None:
@@ -146,14 +162,28 @@ class StepAlgorithm:
         scr = _lib.scratch(dev)
         _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A), lda, _ptr(X), ldx, m, d, _ptr(AT), _ptr(XT),
                                                      _ptr(nrm2), mp, st))
-        seed = StepAlgorithm.stochastic_seed
-        if mode == _lib.MODE_STOCHASTIC:
-            StepAlgorithm.stochastic_seed += 1
-        _lib.check(_lib.lib.gpfq_quantization_f32(
-            _ptr(Wv), ldw, _ptr(Qv), ldq, _ptr(Uv), ldu, 1, _ptr(AT), _ptr(XT), _ptr(nrm2), N, d, m, mp,
-            float(step_size), int(boundary_idx), mode, float(lamb if lamb is not None else 0.0), seed, 0,
-            None, 0, 1, StepAlgorithm.plan, _ptr(scr), scr.numel(), st))
-        _lib.check_status(dev)
+        if seed is None:
+            seed = _default_seeds.take() if mode == _lib.MODE_STOCHASTIC else 0
+        plan = _lib.PLAN_AUTO if plan is None else int(plan)
+        U0 = None
+
+        def launch(pl):
+            _lib.check(_lib.lib.gpfq_quantization_f32(
+                _ptr(Wv), ldw, _ptr(Qv), ldq, _ptr(Uv), ldu, 1, _ptr(AT), _ptr(XT), _ptr(nrm2), N, d, m, mp,
+                float(step_size), int(boundary_idx), mode, float(lamb if lamb is not None else 0.0), int(seed), 0,
+                None, 0, 1, None, pl, _ptr(scr), scr.numel(), st))
+            return bool(_lib.lib.gpfq_last_launch_used_exchange())
+
+        if plan != _lib.PLAN_STREAM_ROWS and N > 0 and d > 0:
+            # this surface updates U in place, so a launch that gives up waiting for a peer workgroup has already
+            # spoilt its input: keep a copy whenever the plan about to run is one that can time out
+            desc = _lib.describe_plan(N, d, m, 1, _lib.PLAN_STREAM if plan == _lib.PLAN_AUTO else plan)
+            if desc.startswith("coop") or " C=" in desc:
+                U0 = Uv.clone()
+        if launch(plan) and not _lib.status_ok(dev):
+            # never hand back what a timed-out launch left behind: redo on the plan that waits for nobody
+            Uv.copy_(U0)
+            launch(_lib.PLAN_STREAM_ROWS)
         if Qv.data_ptr() != Q.data_ptr():
             Q.copy_(Qv)
         if Uv.data_ptr() != U.data_ptr():
@@ -177,8 +207,13 @@ class StepAlgorithm:
 
     def _quantize_layer_ex(W, analog_layer_input, quantized_layer_input, m, step_size, boundary_idx, percentile,
                            reg, lamb, groups, stochastic_quantization, device, compute_errors=True,
-                           step_override=None):
-        '''_quantize_layer with the extra outputs the native path produces.  Returns a dict with
+                           step_override=None, plan=None, seed=None, event_hook=None, check_status=True):
+        '''_quantize_layer with the extra outputs the native path produces.  Per-call options (nothing is read
+        from or left on the class): plan = kernel family (GPFQ_PLAN_*, None = auto); seed = Philox key of the
+        stochastic quantizer (None = next value of a process-wide counter); event_hook = callable(tag, shape)
+        invoked around the column preparation and the loop kernel (bench.py); check_status=False defers the status
+        read of the plans that can time out to the caller (_lib.check_status) -- only for callers that neither
+        consume nor forward the outputs before that.  Returns a dict with
         Q (N, d_g) fp32, idx (N, d_g) int8/int16 alphabet indices, U (local rows of the residual), step,
         and, if compute_errors, quantize_error / relative_quantize_error / quantize_adder / relative_adder.
         When neuron sharding is enabled (dist.enable) W's rows are split over the ranks, the index shards are
@@ -220,9 +255,10 @@ class StepAlgorithm:
             mode = _lib.MODE_HARD
         else:
             mode = _lib.MODE_STOCHASTIC if stochastic_quantization else _lib.MODE_MSQ
-        seed = StepAlgorithm.stochastic_seed
-        if mode == _lib.MODE_STOCHASTIC:
-            StepAlgorithm.stochastic_seed += 1
+        if seed is None:
+            seed = _default_seeds.take() if mode == _lib.MODE_STOCHASTIC else 0
+        seed = int(seed)
+        plan = _lib.PLAN_AUTO if plan is None else int(plan)
         idx_dtype, idx_bytes = _idx_dtype(K)
         dev = W.device
         st = _lib.current_stream_ptr(dev)
@@ -234,15 +270,17 @@ class StepAlgorithm:
             Q = torch.empty((Nl, dg), device=dev, dtype=torch.float32)
             idx = torch.empty((Nl, dg), device=dev, dtype=idx_dtype)
             U = torch.empty((Nl, mm), device=dev, dtype=torch.float32)
+            mp = _lib.lib.gpfq_padded_m(mm)
+            # per-segment sums of squares of the final residual, written by the loop kernel's last step (f2 epilogue)
+            usq_seg = torch.empty((Nl, mp // 1024), device=dev, dtype=torch.float32)
             if Nl == 0 or dg == 0:
-                Q.zero_(); idx.zero_(); U.zero_()
-                return Q, idx, U
+                Q.zero_(); idx.zero_(); U.zero_(); usq_seg.zero_()
+                return Q, idx, U, usq_seg
             # the two halves of gpfq_quantize_layer_f32, called separately so that a profiler hook can
             # bracket the column preparation and the loop kernel with events on the current stream
             D = groups_loc * dg
-            mp = _lib.lib.gpfq_padded_m(mm)
             nrm2 = torch.empty((D,), device=dev, dtype=torch.float32)
-            hook = StepAlgorithm.event_hook
+            hook = event_hook
             if hook:
                 hook("prepare_begin", (Nl, dg, mm, groups_loc))
             if prepared:
@@ -258,46 +296,59 @@ class StepAlgorithm:
                                                              _ptr(AT), _ptr(XT), _ptr(nrm2), mp, st))
             if hook:
                 hook("loop_begin", (Nl, dg, mm, groups_loc))
-            _lib.check(_lib.lib.gpfq_quantize_groups_prepared_f32(
-                _ptr(W_loc), _ptr(Q), _ptr(U), _ptr(AT), _ptr(XT), _ptr(nrm2), Nl, dg, mm, mp, groups_loc,
-                step, K, mode, lamb_f, seed, int(row_id0), _ptr(idx), idx_bytes, StepAlgorithm.plan,
-                _ptr(scr), scr.numel(), st))
+            def launch(pl):
+                _lib.check(_lib.lib.gpfq_quantize_groups_prepared_f32(
+                    _ptr(W_loc), _ptr(Q), _ptr(U), _ptr(AT), _ptr(XT), _ptr(nrm2), Nl, dg, mm, mp, groups_loc,
+                    step, K, mode, lamb_f, seed, int(row_id0), _ptr(idx), idx_bytes, _ptr(usq_seg), pl,
+                    _ptr(scr), scr.numel(), st))
+                return bool(_lib.lib.gpfq_last_launch_used_exchange())
+
+            waits = launch(plan)
             if hook:
                 hook("loop_end", (Nl, dg, mm, groups_loc))
-            return Q, idx, U
+            # A plan whose workgroups wait for each other can give up (bounded spins: another process on the card can
+            # break co-residency).  Its outputs are not handed on -- to the caller, to the all_gather -- before the
+            # status word has been read, and a timed-out layer is redone on the plan that waits for nobody.  The other
+            # plans (resident, wave, whole-row streaming) cannot time out and cost no synchronisation here.
+            if waits and check_status and not _lib.status_ok(dev):
+                timeouts.append((Nl, dg, mm))
+                launch(_lib.PLAN_STREAM_ROWS)
+            return Q, idx, U, usq_seg
 
+        timeouts = []
         shard = _dist.active()
         if shard is None:
-            Q, idx, U = run_rows(W, groups, A, lda, X, ldx, 0)
+            Q, idx, U, usq_seg = run_rows(W, groups, A, lda, X, ldx, 0)
             rows = None
         else:
-            Q, idx, U, rows = _dist.quantize_sharded(shard, W, A, lda, X, ldx, groups, dg, step, K, mode, lamb_f,
-                                                     idx_dtype, run_rows)
-        out = dict(Q=Q, idx=idx, U=U, step=step_t, rows=rows)
+            Q, idx, U, usq_seg, rows = _dist.quantize_sharded(shard, W, A, lda, X, ldx, groups, dg, step, K, mode,
+                                                              lamb_f, idx_dtype, run_rows)
+        out = dict(Q=Q, idx=idx, U=U, usq_seg=usq_seg, step=step_t, rows=rows, timeouts=timeouts)
         if compute_errors:
-            _lib.check_status(dev)      # synchronises; raises if a cooperative kernel timed out
-            out.update(StepAlgorithm._error_metrics(W, A, U, groups, rows, shard))
+            out.update(StepAlgorithm._error_metrics(W, A, usq_seg, groups, rows, shard, U))
         return out
 
-    def _error_metrics(W, A, U, groups, rows, shard):
+    def _error_metrics(W, A, usq_seg, groups, rows, shard, U):
         '''step_algorithm.py:216-219 (groups == 1) and :239-243 (mean over groups of per-group norms).
-        A @ W.T is one MFMA GEMM (torch.matmul -> hipBLASLt), computed once instead of twice.'''
+        ||U[i, :]||^2 comes out of the loop kernel (usq_seg: its last step leaves one sum of squares per 1024-element
+        segment; the few segments of a row are added here in float64), so U itself is not read again; A @ W.T is one
+        MFMA GEMM (torch.matmul -> hipBLASLt), computed once instead of the reference's twice.'''
         if isinstance(A, PreparedColumns):
             A = A.matrix()
         N, dg = W.shape
         mm = A.shape[0]
+        usq = usq_seg.double().sum(1)                                      # (rows,)  ||U[i, :]||^2
         if shard is not None:
-            return _dist.sharded_error_metrics(shard, W, A, U, groups, rows)
+            return _dist.sharded_error_metrics(shard, W, A, usq, groups, rows, U)
         if groups == 1:
             quantize_adder = U.T
             AW = A @ W.T
-            relative_adder = torch.linalg.norm(quantize_adder, axis=0) / (torch.linalg.norm(AW, axis=0) + 1e-5)
-            quantize_error = torch.linalg.norm(quantize_adder, ord='fro')
+            relative_adder = (usq.sqrt() / (torch.linalg.norm(AW, axis=0).double() + 1e-5)).float()
+            quantize_error = usq.sum().sqrt().float()
             relative_quantize_error = quantize_error / torch.linalg.norm(AW, ord='fro')
         else:
             Ng = N // groups
-            U3 = U.view(groups, Ng, mm)
-            un = torch.linalg.norm(U3.reshape(groups, -1), dim=1)
+            un = usq.view(groups, Ng).sum(1).sqrt().float()
             A3 = A.reshape(mm, groups, dg).permute(1, 0, 2)                # (g, m, d_g)
             AW = torch.bmm(A3, W.view(groups, Ng, dg).transpose(1, 2))      # (g, m, Ng)
             an = torch.linalg.norm(AW.reshape(groups, -1), dim=1)
@@ -322,8 +373,4 @@ class StepAlgorithm:
         r = StepAlgorithm._quantize_layer_ex(W, analog_layer_input, quantized_layer_input, m, step_size,
                                              boundary_idx, percentile, reg, lamb, groups,
                                              stochastic_quantization, device)
-        StepAlgorithm.last_result = r
         return r["Q"], r["quantize_error"], r["relative_quantize_error"], r["quantize_adder"], r["relative_adder"]
-
-
-StepAlgorithm.last_result = None

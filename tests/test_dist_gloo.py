@@ -22,13 +22,13 @@ def _free_port():
     return p
 
 
-def _oracle_run_rows(step, K, mode, lamb, m, dg):
+def _oracle_run_rows(step, K, mode, lamb, m, dg, seed=0):
     import oracle
 
     def run_rows(W_loc, groups_loc, A_loc, lda, X_loc, ldx, row_id0):
         Nl = W_loc.shape[0]
         if Nl == 0:
-            return (torch.zeros(0, dg), torch.zeros(0, dg, dtype=torch.int8), torch.zeros(0, m))
+            return (torch.zeros(0, dg), torch.zeros(0, dg, dtype=torch.int8), torch.zeros(0, m), torch.zeros(0, 1))
         Wn = W_loc.contiguous().numpy()
         An = np.ascontiguousarray(A_loc.numpy())
         Xn = np.ascontiguousarray(X_loc.numpy())
@@ -38,9 +38,11 @@ def _oracle_run_rows(step, K, mode, lamb, m, dg):
         U = np.zeros((Nl, m), np.float32)
         for g in range(groups_loc):
             q, i, u = oracle.quantization(Wn[g * Ng:(g + 1) * Ng], An[:, g * dg:(g + 1) * dg], Xn[:, g * dg:(g + 1) * dg],
-                                          step, K, mode=mode, lamb=lamb, nthreads=1)
+                                          step, K, mode=mode, lamb=lamb, nthreads=1, seed=seed,
+                                          row_id0=int(row_id0) + g * Ng)      # as the kernels: key = row_id0 + local row
             Q[g * Ng:(g + 1) * Ng], idx[g * Ng:(g + 1) * Ng], U[g * Ng:(g + 1) * Ng] = q, i, u
-        return torch.from_numpy(Q), torch.from_numpy(idx.astype(np.int8)), torch.from_numpy(U)
+        usq_seg = (torch.from_numpy(U).double() ** 2).sum(1, keepdim=True).float()   # one "segment" per row here
+        return torch.from_numpy(Q), torch.from_numpy(idx.astype(np.int8)), torch.from_numpy(U), usq_seg
     return run_rows
 
 
@@ -63,10 +65,19 @@ def _worker(rank, world, port, case_name, out_dir):
         ctx = qd.enable()
         assert qd.active() is ctx and ctx.world == world
         Wt, At, Xt = torch.from_numpy(W), torch.from_numpy(A), torch.from_numpy(X)
-        Q, idx, U_loc, rows = qd.quantize_sharded(ctx, Wt, At, At.shape[1], Xt, Xt.shape[1], groups, dg, step, K, mode,
-                                                  float(np.float32(case["lamb"])), torch.int8,
-                                                  _oracle_run_rows(step, K, mode, case["lamb"], m, dg))
-        met = qd.sharded_error_metrics(ctx, Wt, At, U_loc, groups, rows)
+        Q, idx, U_loc, usq_seg, rows = qd.quantize_sharded(ctx, Wt, At, At.shape[1], Xt, Xt.shape[1], groups, dg, step, K,
+                                                           mode, float(np.float32(case["lamb"])), torch.int8,
+                                                           _oracle_run_rows(step, K, mode, case["lamb"], m, dg))
+        met = qd.sharded_error_metrics(ctx, Wt, At, usq_seg.double().sum(1), groups, rows, U_loc)
+        # stochastic quantizer: the Philox keys are the GLOBAL row numbers, so the sharded draw equals the unsharded one
+        # (this is what used to break for 1 < groups < world)
+        Ngf = W.shape[0] // groups
+        full = np.concatenate([oracle.quantization(W[g * Ngf:(g + 1) * Ngf], A[:, g * dg:(g + 1) * dg], X[:, g * dg:(g + 1) * dg],
+                                                   step, K, mode=3, nthreads=1, seed=5, row_id0=g * Ngf)[1]
+                               for g in range(groups)], 0)
+        _, idx_s, _, _, _ = qd.quantize_sharded(ctx, Wt, At, At.shape[1], Xt, Xt.shape[1], groups, dg, step, K, 3, 0.0,
+                                                torch.int8, _oracle_run_rows(step, K, 3, 0.0, m, dg, seed=5))
+        assert np.array_equal(idx_s.numpy().astype(np.int16), full), "stochastic shard != unsharded draw"
         # every rank holds the full gathered result
         assert np.array_equal(idx.numpy().astype(np.int16), fx["idx"]), "gathered indices differ from the reference"
         assert np.array_equal(Q.numpy(), fx["Q"])

@@ -74,3 +74,22 @@ def test_bench_runs_sharded(tmp_path):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "strong"
     assert rec["roofline"]["kernel"].startswith("gpfq_")
+    assert rec["output_check"]["mismatches"] == 0 and rec["output_check"]["layers"] == 2
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (what the driver's scaling run does): bench.py starts
+    torch.distributed.run itself as a child process before touching the GPU, relays the JSON line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--backend", "gloo",
+           "--share-gpu", "--layers", "layer4.1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["roofline"] is not None and rec["roofline_l2"] is not None
+    assert rec["output_check"]["mismatches"] == 0
+    # and a child that fails makes the parent fail (no silent rc 0)
+    bad = subprocess.run(cmd + ["--plan", "9"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert bad.returncode != 0

@@ -165,3 +165,72 @@ def test_packed_checkpoint_round_trip_is_bitwise(ci, tmp_path):
     assert set(want) == set(got)
     for k in want:
         assert torch.equal(want[k].cpu(), got[k]), k
+
+
+def test_two_quantizers_interleaved_layer_by_layer():
+    """No class-level state travels between StepAlgorithm calls: two QuantizeNeuralNet instances whose layers are
+    quantized alternately (config 0 and config 1 of the G5 fixture) each reproduce the reference's weights, and each
+    records ITS OWN indices for the packed checkpoint."""
+    from quantized_neural_nets_amd import QuantizeNeuralNet, dist as qd
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g5_driver.npz"))
+    metas = json.loads(str(fx["meta"]))["configs"]
+    dev = torch.device("cuda:0")
+    quants, streams = [], []
+    for ci in (0, 1):
+        meta, cfg = metas[ci], metas[ci]["cfg"]
+        rng = np.random.default_rng(meta["net_seed"])
+        net = gi.toy_net(rng).to(dev)
+        batches = gi.toy_batches(rng, meta["batch"], meta["nlayers"])
+        quants.append(QuantizeNeuralNet(net, "toy", meta["batch"], batches, mlp_bits=cfg["bits"], cnn_bits=cfg["bits"],
+                                        ignore_layers=[], mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16,
+                                        mlp_percentile=1, cnn_percentile=1, reg=cfg["reg"], lamb=cfg["lamb"],
+                                        retain_rate=cfg["retain_rate"], stochastic_quantization=False, device=dev))
+        # each instance consumes its own np.random stream, as its own un-interleaved run would
+        st = np.random.RandomState(meta["np_seed"])
+        streams.append(st.get_state())
+    # drive the two layer loops alternately: layer L of A, layer L of B, layer L+1 of A, ...
+    for li in range(metas[0]["nlayers"]):
+        for qi, quant in enumerate(quants):
+            np.random.set_state(streams[qi])
+            saved = quant.ignore_layers
+            quant.ignore_layers = [i for i in range(metas[qi]["nlayers"]) if i != li]
+            # the loader hands one batch per quantized layer (quantize_neural_net.py:227): skip none
+            quant.quantize_network()
+            quant.ignore_layers = saved
+            streams[qi] = np.random.get_state()
+    for qi, quant in enumerate(quants):
+        for li, layer in enumerate(quant.quantized_network_layers):
+            assert np.array_equal(layer.weight.detach().cpu().numpy(), fx["c%d_layer%d_weight" % (qi, li)]), (qi, li)
+        assert [e["layer"] for e in quant.layer_indices] == list(range(metas[qi]["nlayers"]))
+        for e, layer in zip(quant.layer_indices, quant.quantized_network_layers):
+            q = qd.rebuild_q(e["idx"], e["step"], e["K"], e["mode"], e["lamb"]).reshape(layer.weight.shape)
+            assert torch.equal(q, layer.weight.detach().cpu()), "instance %d recorded another layer's indices" % qi
+
+
+def test_cooperative_timeout_falls_back_to_whole_row_streaming(monkeypatch, oracle_mod):
+    """A cooperative launch that gives up waiting for a peer (forced: spin limit 0) never hands its outputs on: the
+    status word is read before anything is consumed and the layer is redone on GPFQ_PLAN_STREAM_ROWS."""
+    from quantized_neural_nets_amd import StepAlgorithm as SA, _lib
+    case = dict(name="timeout", N=16, d=24, m=40000, bits=4, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,
+                first_layer=False, zero_every=0, seed=4)
+    W, A, X = gi.make_inputs(case)
+    dev = torch.device("cuda:0")
+    assert _lib.describe_plan(16, 24, 40000).startswith("coop")
+    monkeypatch.setenv("GPFQ_COOP_SPIN_LIMIT", "0")
+    r = SA._quantize_layer_ex(torch.from_numpy(W).to(dev), torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev),
+                              40000, 1.16 / 8, 8, 1.0, None, 0.0, 1, False, dev)
+    monkeypatch.delenv("GPFQ_COOP_SPIN_LIMIT")
+    assert r["timeouts"] == [(16, 24, 40000)]
+    o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+    assert abs(float(r["quantize_error"]) - o["quantize_error"]) <= 1e-4 * o["quantize_error"]
+    _lib.check_status(dev)                          # the status word was consumed by the fallback
+    # the in-place surface: U must be restored before the redo
+    Q = torch.zeros(16, 24, device=dev)
+    U = torch.zeros(16, 40000, device=dev)
+    monkeypatch.setenv("GPFQ_COOP_SPIN_LIMIT", "0")
+    monkeypatch.setenv("GPFQ_STREAM_C", "4"); monkeypatch.setenv("GPFQ_STREAM_RT", "4")
+    SA._quantization(torch.from_numpy(W).to(dev), Q, U, torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev), SA._msq,
+                     float(r["step"]), 8, 0.0)
+    assert np.array_equal(U.cpu().numpy(), o["U"]) and np.array_equal(Q.cpu().numpy(), o["Q"])

@@ -17,12 +17,8 @@ def _layer(qnn_plan, shape, seed, rows=None, d_limit=None):
     Wd = W.to(DEV)
     if rows is not None:
         Wd = Wd[rows[0]:rows[1]].contiguous()
-    SA.plan = qnn_plan
-    try:
-        r = SA._quantize_layer_ex(Wd, A.to(DEV), X.to(DEV), m, 1.16 / 8, 8, 1, None, 0.1, 1, False,
-                                  torch.device(DEV), step_override=bw.layer_step(W))
-    finally:
-        SA.plan = 0
+    r = SA._quantize_layer_ex(Wd, A.to(DEV), X.to(DEV), m, 1.16 / 8, 8, 1, None, 0.1, 1, False,
+                              torch.device(DEV), step_override=bw.layer_step(W), plan=qnn_plan)
     torch.cuda.synchronize()
     return W, A, X, r
 
@@ -68,3 +64,32 @@ def test_full_size_layer_against_oracle(oracle_mod):
     Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8)
     assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
     assert np.array_equal(r["U"].cpu().numpy(), U)
+
+
+@pytest.mark.parametrize("shape,kernel", [((128, 1152, 93184), "coop RT=4 C=8"), ((256, 2304, 26624), "coop RT=4 C=4")])
+def test_full_size_four_row_cooperative_shapes(oracle_mod, shape, kernel):
+    """ResNet-50 layer2.0.conv2 and layer3.0.conv2 at batch 1024 -- the two headline shapes the four-row cooperative
+    kernels carry -- at FULL d: AUTO == streaming bit for bit (indices, Q, U), the fused sum-of-squares epilogue
+    equals a pass over U, and the first 256 columns equal the CPU oracle bit for bit."""
+    from quantized_neural_nets_amd import _lib
+    assert _lib.describe_plan(*shape).startswith(kernel), _lib.describe_plan(*shape)
+    W, A, X, full = _layer(0, shape, 1234 + 11)
+    assert full["timeouts"] == []
+    _, _, _, st = _layer(1, shape, 1234 + 11)
+    assert torch.equal(st["idx"], full["idx"]) and torch.equal(st["U"], full["U"]) and torch.equal(st["Q"], full["Q"])
+    usq = full["usq_seg"].double().sum(1)
+    ref = (full["U"].double() ** 2).sum(1)
+    assert torch.allclose(usq, ref, rtol=1e-5)
+    assert torch.equal(st["usq_seg"], full["usq_seg"])            # same canonical order in every kernel family
+    del st
+    W2, A2, X2, part = _layer(0, shape, 1234 + 11, d_limit=256)
+    Q, idx, U = oracle_mod.quantization(W2.numpy(), A2.numpy(), X2.numpy(), float(part["step"]), 8)
+    assert np.array_equal(part["idx"].cpu().numpy().astype(np.int16), idx)
+    assert np.array_equal(part["U"].cpu().numpy(), U)
+    # a truncated run is a prefix of the full run only if the step is the same: it is not (the step comes from W's
+    # row maxima over the columns kept), so the prefix property is checked with the full run's step instead
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    pre = SA._quantize_layer_ex(W[:, :256].contiguous().to(DEV), A[:, :256].contiguous().to(DEV),
+                                X[:, :256].contiguous().to(DEV), shape[2], 1.16 / 8, 8, 1, None, 0.1, 1, False,
+                                torch.device(DEV), step_override=float(full["step"]), compute_errors=False)
+    assert torch.equal(pre["idx"], full["idx"][:, :256])

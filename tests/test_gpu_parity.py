@@ -38,13 +38,9 @@ def _run_layer(qnn, case, W, A, X, plan=0):
             _lib.describe_plan(W.shape[0], W.shape[1], A.shape[0], case["groups"], 3)
         except _lib.GpfqError:
             pytest.skip("cooperative plan does not apply to this shape")
-    StepAlgorithm.plan = plan
-    try:
-        r = StepAlgorithm._quantize_layer_ex(_t(W), _t(A), _t(X), A.shape[0], case["scalar"] / K, K,
-                                             case["percentile"], case["reg"], case["lamb"], case["groups"], False,
-                                             torch.device(DEV))
-    finally:
-        StepAlgorithm.plan = 0
+    r = StepAlgorithm._quantize_layer_ex(_t(W), _t(A), _t(X), A.shape[0], case["scalar"] / K, K,
+                                         case["percentile"], case["reg"], case["lamb"], case["groups"], False,
+                                         torch.device(DEV), plan=plan)
     torch.cuda.synchronize()
     return r
 
@@ -299,8 +295,7 @@ def test_quantization_in_place_with_initial_residual_and_views(qnn, oracle_mod):
 def test_stochastic_loop_matches_oracle_bitwise(qnn, oracle_mod):
     from quantized_neural_nets_amd import StepAlgorithm as SA
     case, (W, A, X), fx, _ = gi.load_case("g2_16x64x96_msq_b4")
-    SA.stochastic_seed = 77
-    r = SA._quantize_layer_ex(_t(W), _t(A), _t(X), 96, 1.16 / 8, 8, 1.0, None, 0.0, 1, True, torch.device(DEV))
+    r = SA._quantize_layer_ex(_t(W), _t(A), _t(X), 96, 1.16 / 8, 8, 1.0, None, 0.0, 1, True, torch.device(DEV), seed=77)
     torch.cuda.synchronize()
     Q, idx, U = oracle_mod.quantization(W, A, X, float(r["step"]), 8, mode=oracle_mod.MODE_STOCHASTIC, seed=77)
     assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)

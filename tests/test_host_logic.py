@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(raw, name), "libgpfq_hip.so does not export " + name
     assert declared == set(lib.EXPORTS), (declared ^ set(lib.EXPORTS))
-    assert lib.lib.gpfq_abi_version() == 1
+    assert lib.lib.gpfq_abi_version() == 2
 
 
 def test_padding_and_workspace(lib):
@@ -49,12 +49,12 @@ def test_host_side_argument_errors_need_no_gpu(lib):
     assert L.gpfq_row_absmax_f32(one, 3, 4, 8, one, None) == -1                      # ldw < d
     assert L.gpfq_prepare_columns_f32(one, 8, one, 8, 100, 8, one, one, one, 512, None) == -1   # m_pad wrong
     assert b"m_pad" in L.gpfq_last_error()
-    rc = L.gpfq_quantize_layer_f32(one, one, 32, one, 32, 6, 8, 100, 4, 0.1, 8, 0, 0.0, 0, 0, one, None, 1, one, one, 1 << 30, 0, None)
+    rc = L.gpfq_quantize_layer_f32(one, one, 32, one, 32, 6, 8, 100, 4, 0.1, 8, 0, 0.0, 0, 0, one, None, 1, one, None, one, 1 << 30, 0, None)
     assert rc == -1 and b"divisible" in L.gpfq_last_error()                           # N % groups
-    rc = L.gpfq_quantize_layer_f32(one, one, 8, one, 8, 8, 8, 100, 1, 0.1, 8, 0, 0.0, 0, 0, one, None, 1, one, one, 16, 0, None)
+    rc = L.gpfq_quantize_layer_f32(one, one, 8, one, 8, 8, 8, 100, 1, 0.1, 8, 0, 0.0, 0, 0, one, None, 1, one, None, one, 16, 0, None)
     assert rc == -2                                                                   # workspace too small
     rc = L.gpfq_quantize_groups_prepared_f32(one, one, one, one, one, one, 8, 8, 100, 1024, 1, 0.1, 200, 0, 0.0, 0, 0,
-                                             one, 1, 0, None, 0, None)
+                                             one, 1, None, 0, None, 0, None)
     assert rc == -1 and b"int8" in L.gpfq_last_error()                                # K too big for int8
 
 
@@ -72,6 +72,10 @@ def test_plan_selection(lib):
     assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=4 C=2 waves=7")      # long rows, more rows than CUs
     assert lib.describe_plan(64, 9, 30000, 64).startswith("stream")                     # grouped: never cooperative
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
+    # the fallback plan: whole rows per workgroup, never an exchange, whatever the shape
+    for shape in ((64, 576, 93184), (8, 576, 93184), (512, 4608, 3072), (256, 2304, 803840)):
+        desc = lib.describe_plan(*shape, 1, lib.PLAN_STREAM_ROWS)
+        assert desc.startswith("stream") and " C=" not in desc, desc
     with pytest.raises(lib.GpfqError):
         lib.describe_plan(8, 8, 2_000_000)
 
@@ -134,7 +138,7 @@ def test_extract_layers_order_and_whitelist():
 
 def test_bench_workload_matches_survey_totals():
     import bench_workload as bw
-    L = bw.resnet50_3x3_layers(1024)
+    L = [l[:4] for l in bw.resnet50_3x3_layers(1024)]
     assert len(L) == 16 and sum(n * d for _, n, d, _ in L) == 11317248
     assert abs(sum(bw.algorithmic_bytes(n, d, m) for _, n, d, m in L) / 1e12 - 0.837) < 1e-3
     assert {m for *_, m in L} == {93184, 26624, 7168, 3072}
@@ -147,6 +151,17 @@ def test_bench_workload_matches_survey_totals():
     assert len(V) == 16 and abs(sum(n * d for _, n, d, _ in V) / 1e6 - 138.3) < 0.1
     assert abs(sum(bw.algorithmic_bytes(n, d, m) for _, n, d, m in V) / 1e12 - 2.449) < 5e-3
     assert max(m for *_, m in V) == 720384
+    # BASELINE.json configs[3] and [4]: all 54 ResNet-50 layers; EfficientNet-B1's 116 layers
+    A = bw.normalize_layers(bw.resnet50_all_layers(1024))
+    assert len(A) == 54 and abs(sum(l[1] * l[2] for l in A) / 1e6 - 25.50) < 0.01
+    assert abs(sum(bw.algorithmic_bytes(l[1], l[2], l[3], l[4]) for l in A) / 1e12 - 7.215) < 5e-3
+    E = bw.efficientnet_b1_layers(1024)
+    assert len(E) == 116 and abs(sum(l[1] * l[2] for l in E) / 1e6 - 7.72) < 0.01
+    assert abs(sum(bw.algorithmic_bytes(l[1], l[2], l[3], l[4]) for l in E) / 1e12 - 1.133) < 1e-3
+    dw = [l for l in E if l[4] > 1]
+    assert len(dw) == 23 and all(l[1] == l[4] and l[2] in (9, 25) for l in dw)
+    assert min(l[3] for l in dw) == 2048 and max(l[3] for l in dw) == 370688
+    assert sum(1 for l in E if ".fc" in l[0] and l[3] == 1024) == 46
 
 
 @pytest.mark.parametrize("K,mode", [(1, 0), (2, 1), (4, 0), (8, 0), (8, 2), (2, 2), (64, 3), (200, 0)])

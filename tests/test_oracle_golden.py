@@ -103,3 +103,74 @@ def test_stochastic_mode_statistics(oracle_mod):
     q, idx = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, step, np.array([5.0, -5.0], np.float32), K,
                                       uniform=np.array([0.3, 0.9], np.float32))
     assert list(q) == [1.0, -1.0] and list(idx) == [4, -4]
+
+
+# ---- G6: headline-scale fixtures generated WITHOUT seed search; mismatches go through the tie audit -------------
+def check_big_case(name, got, where):
+    """Compare one implementation's outputs (dict idx / U / step / errors) with a G6 fixture.  Indices: bit-exact,
+    or every diverging row's first divergence is a tie within 1e-5 (tests/tie_audit.py).  Rows that agree must
+    reproduce the reference's residual bit for bit (the update is elementwise)."""
+    import tie_audit
+    case, (W, A, X), fx, meta = gi.load_big_case(name)
+    assert np.float32(got["step"]) == fx["step"]
+    idx = np.asarray(got["idx"]).astype(np.int16)
+    rep = tie_audit.assert_parity(case, W, A, X, fx["step"], fx["idx"], idx, tol=1e-5, what="%s vs reference %s" % (where, name))
+    ok = rep["agreeing_rows"]
+    # more than a handful of tie rows would mean the reduction is noisier than a BLAS-order difference explains
+    assert rep["rows_diverged"] <= max(2, case["N"] // 50), rep["ties"]
+    ck = gi.row_checksums(np.asarray(got["U"]))
+    assert np.array_equal(ck["U_crc32"][ok], fx["U_crc32"][ok]), "residual rows differ from the reference where indices agree"
+    assert np.array_equal(ck["U_head"][ok], fx["U_head"][ok])
+    if not rep["rows_diverged"]:
+        qe = float(np.sqrt(ck["U_sumsq"].sum()))
+        assert abs(qe - float(fx["quantize_error"])) <= 1e-4 * float(fx["quantize_error"])
+        if got.get("quantize_error") is not None:
+            assert abs(float(got["quantize_error"]) - float(fx["quantize_error"])) <= 1e-4 * float(fx["quantize_error"])
+            assert abs(float(got["relative_quantize_error"]) - float(fx["relative_quantize_error"])) <= 1e-4 * float(
+                fx["relative_quantize_error"])
+        if got.get("relative_adder") is not None:
+            assert np.allclose(np.asarray(got["relative_adder"]), fx["relative_adder"], rtol=1e-4, atol=1e-6)
+    print("%s %s: %d weights, %d/%d rows diverge at a tie (margins %s), fixture fp64 margin %.2e" % (
+        where, name, rep["weights"], rep["rows_diverged"], rep["rows_compared"],
+        ["%.1e" % t["margin"] for t in rep["ties"]], meta["margin"]))
+    return rep
+
+
+def test_big_fixtures_present():
+    assert gi.available_big_cases() == sorted(gi.BIG_CASES), "run tools/make_golden.py --only g6_ in the build container"
+    for name in gi.BIG_CASES:
+        meta = json.loads(str(np.load(os.path.join(gi.GOLDEN_DIR, name + ".npz"))["meta"]))
+        assert meta["seed_search"] is False and meta["seed_offset"] == 0
+
+
+@pytest.mark.parametrize("name", sorted(gi.BIG_CASES))
+def test_big_case_against_reference(oracle_mod, name):
+    case, (W, A, X), fx, meta = gi.load_big_case(name)
+    K = 2 ** (case["bits"] - 1)
+    r = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"], 1)
+    check_big_case(name, r, "oracle")
+
+
+def test_tie_audit_rejects_a_real_mismatch_and_accepts_a_tie():
+    """The comparator itself: a flipped index far from a boundary is a failure; an index moved across a boundary
+    that the rounding argument sits on (constructed) is a tie."""
+    import tie_audit
+    case, (W, A, X), fx, _ = gi.load_case("g2_16x64x96_msq_b4")
+    idx = fx["idx"].copy()
+    bad = idx.copy()
+    bad[3, 10] += 1 if bad[3, 10] < 8 else -1
+    rep = tie_audit.audit(case, W, A, X, fx["step"], idx, bad)
+    assert rep["rows_diverged"] == 1 and len(rep["unexplained"]) == 1 and rep["unexplained"][0]["col"] == 10
+    assert rep["unexplained"][0]["margin"] > 1e-4            # the fixture's own margin
+    with pytest.raises(AssertionError):
+        tie_audit.assert_parity(case, W, A, X, fx["step"], idx, bad)
+    jump = idx.copy()
+    jump[5, 0] += 2 if jump[5, 0] < 7 else -2                # not even a neighbour
+    assert tie_audit.audit(case, W, A, X, fx["step"], idx, jump)["unexplained"][0]["margin"] == float("inf")
+    # a constructed tie: one weight, one sample, s = w*a*x/x^2 exactly half-way between two levels
+    c1 = dict(bits=4, reg=None, lamb=0.0, groups=1)
+    W1 = np.array([[1.5]], np.float32); A1 = np.array([[1.0]], np.float32); X1 = np.array([[1.0]], np.float32)
+    rep = tie_audit.audit(c1, W1, A1, X1, 1.0, np.array([[2]]), np.array([[1]]))
+    assert rep["ties"] and rep["ties"][0]["margin"] == 0.0 and not rep["unexplained"]
+    assert tie_audit.boundary_margin(0.5, 1.0, 8, 0.5, "L0", 0, 1) == 0.0
+    assert tie_audit.boundary_margin(-2.0, 1.0, 8, 0.5, "L0", -2, -3) == pytest.approx(0.0)   # (|s|-lamb)/step = 1.5

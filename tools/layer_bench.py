@@ -32,21 +32,20 @@ def main():
                 if k.startswith("GPFQ_") and k != "GPFQ_LIB_OVERRIDE":
                     del os.environ[k]
             os.environ.update(kv)
-            StepAlgorithm.plan = plan
             ev = []
 
             def hook(tag, shape):
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 ev.append(e)
-            StepAlgorithm.event_hook = hook
             try:
                 desc = _lib.describe_plan(N, dl, m, 1, plan)
                 best = 1e9
                 for it in range(4):
                     del ev[:]
                     r = StepAlgorithm._quantize_layer_ex(W, A, X, m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev,
-                                                         compute_errors=False, step_override=step)
+                                                         compute_errors=False, step_override=step, plan=plan,
+                                                         event_hook=hook)
                     torch.cuda.synchronize()
                     best = min(best, ev[1].elapsed_time(ev[2]))
                 _lib.check_status(dev)

@@ -12,6 +12,7 @@ What is called (reference paths relative to /root/reference/src):
   StepAlgorithm._quantize_layer                                     step_algorithm.py:151-249  -> g2/g3/g4 *.npz
   StepAlgorithm._quantization (per group, for the residual U)       step_algorithm.py:107-148
   QuantizeNeuralNet(...).quantize_network()                         quantize_neural_net.py:32-214 -> g5_driver.npz
+  StepAlgorithm._quantize_layer at headline scale, NO seed search   step_algorithm.py:151-249  -> g6_*.npz (idx + U digests)
 """
 import argparse
 import io
@@ -189,6 +190,38 @@ def gen_loop_case(SA, name):
         name, off, margin, res["step"], len(np.unique(idx)), np.abs(res["U"]).max()))
 
 
+# ------------------------------------------------------------------------------------------------ G6
+def gen_big_case(SA, name):
+    """Headline-scale case: ONE run of the reference on seed offset 0 -- no seed search, no margin requirement.
+    Stores int8 indices, the step, the error outputs and per-row digests of U (gi.row_checksums) instead of Q / U."""
+    case = gi.BIG_CASES[name]
+    assert case["groups"] == 1
+    W, A, X = gi.make_inputs(case, 0)
+    N, d, m = case["N"], case["d"], case["m"]
+    K = 2 ** (case["bits"] - 1)
+    step_base = case["scalar"] / K
+    Wt, At, Xt = torch.from_numpy(W.copy()), torch.from_numpy(A.copy()), torch.from_numpy(X.copy())
+    t0 = time.time()
+    Q, qe, rqe, adder, radder = quiet(SA._quantize_layer, Wt, At, Xt, m, step_base, K, case["percentile"],
+                                      case["reg"], case["lamb"], 1, False, torch.device("cpu"))
+    dt = time.time() - t0
+    rad = torch.quantile(torch.abs(Wt), case["percentile"], axis=1).mean()
+    step = step_base * rad - case["lamb"] / K if case["reg"] == 'L0' else step_base * rad
+    Q = Q.numpy().reshape(N, d)
+    U = adder.T.contiguous().numpy()            # quantize_adder = U.T  (step_algorithm.py:216)
+    idx = index_of(case, Q, step.item())
+    assert np.abs(idx).max() <= 127
+    margin = fp64_margin(case, W, A, X, Q, step.item())
+    meta = dict(case=case, seed_offset=0, seed_search=False, inputs_sha256=gi.inputs_digest(W, A, X), margin=margin,
+                reference_seconds=dt, provenance=provenance())
+    np.savez_compressed(os.path.join(gi.GOLDEN_DIR, name + ".npz"), meta=np.array(json.dumps(meta)),
+                        idx=idx.astype(np.int8), step=np.float32(step.item()),
+                        quantize_error=np.float32(float(qe)), relative_quantize_error=np.float32(float(rqe)),
+                        relative_adder=radder.numpy().copy(), **gi.row_checksums(U))
+    print("%-30s NO seed search: fp64 margin=%.2e step=%.6g levels=%d ref %.1fs (%.4f Mw/s, %d threads)" % (
+        name, margin, step.item(), len(np.unique(idx)), dt, N * d / dt / 1e6, torch.get_num_threads()))
+
+
 # ------------------------------------------------------------------------------------------------ G5
 def import_reference_driver():
     """quantize_neural_net.py imports torchvision (unused) and utils.py imports torchvision block classes
@@ -268,6 +301,7 @@ def main():
     ap.add_argument("--bench", action="store_true")
     ap.add_argument("--only", default=None, help="substring filter on case names")
     ap.add_argument("--skip-driver", action="store_true")
+    ap.add_argument("--skip-big", action="store_true", help="skip the headline-scale G6 cases (minutes of reference time)")
     args = ap.parse_args()
     if not os.path.isdir(REF_SRC):
         sys.exit("reference not present: this tool only runs in the build container")
@@ -279,6 +313,9 @@ def main():
     for name in gi.CASES:
         if args.only is None or args.only in name:
             gen_loop_case(SA, name)
+    for name in gi.BIG_CASES:
+        if (args.only is None and not args.skip_big) or (args.only is not None and args.only in name):
+            gen_big_case(SA, name)
     if not args.skip_driver and args.only is None:
         gen_driver()
     if args.bench:

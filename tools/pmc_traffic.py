@@ -34,7 +34,16 @@ def main():
         write_kb = w[k][1] / w[k][0] if k in w else 0.0
         out[k] = {"launches": n, "FETCH_SIZE_KB_avg": round(fetch_kb, 1), "WRITE_SIZE_KB_avg": round(write_kb, 1),
                   "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024)}
-    json.dump({"command": "python bench.py --steps 1 --warmup 1 --no-cpu-baseline",
+    import importlib.util
+    import os
+    # the digest of the kernel sources these counters were collected on (bench.py refuses a summary of other sources);
+    # the module is loaded by path so that neither torch nor the built library is needed here
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_digest", os.path.join(root, "quantized_neural_nets_amd", "_digest.py"))
+    dg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dg)
+    json.dump({"command": "python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-output-check",
+               "source_sha256": dg.kernel_source_digest(),
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes (gfx950 FETCH_SIZE correction)", "kernels": out},
               sys.stdout, indent=1)
 

@@ -50,15 +50,11 @@ def main():
                     seed=int(rng.integers(0, 1 << 30)))
         W, A, X = gi.make_inputs(case)
         K = 2 ** (bits - 1)
-        StepAlgorithm.plan = plan
-        try:
-            r = StepAlgorithm._quantize_layer_ex(torch.from_numpy(W).to(dev), torch.from_numpy(A).to(dev),
-                                                 torch.from_numpy(X).to(dev), m, 1.16 / K, K, 1.0, reg, 0.02, groups, False,
-                                                 dev, compute_errors=False)
-            torch.cuda.synchronize()
-            _lib.check_status(dev)
-        finally:
-            StepAlgorithm.plan = 0
+        r = StepAlgorithm._quantize_layer_ex(torch.from_numpy(W).to(dev), torch.from_numpy(A).to(dev),
+                                             torch.from_numpy(X).to(dev), m, 1.16 / K, K, 1.0, reg, 0.02, groups, False,
+                                             dev, compute_errors=False, plan=plan)
+        torch.cuda.synchronize()
+        _lib.check_status(dev)
         o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
         desc = _lib.describe_plan(N, d, m, groups, plan).split()[0]
         kinds[desc] = kinds.get(desc, 0) + 1
