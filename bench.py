@@ -155,7 +155,7 @@ def kernel_name(desc, mode=0):
     if w[0] == "resident":
         if int(kv.get("S", "0")) == 1:
             return "gpfq_wave_kernel<"
-        return "gpfq_resident_kernel<%d, %d>" % (mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
+        return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
         return "gpfq_coop_kernel<%d, %d, %d" % (rt, mode, 8 if waves <= 8 else 12)
     return "gpfq_stream_kernel<%d, true" % rt

@@ -70,6 +70,7 @@ int env_int(const char* name, int dflt)
 }
 
 int slab_max_waves(bool coop, int RT);
+int resident_max_rt(int waves);
 
 // Cost model of one cooperative column step (microseconds): least squares over 50 measured (N, S, RT, C) points on an
 // MI355X (tools/layer_bench.py sweep over the ResNet-50 cooperative shapes and their 2-, 4- and 8-way row shards; rms
@@ -84,15 +85,36 @@ double slab_step_cost(int RT, int waves, int C, int wgs)
            (C >= 64 ? 1.5 : 0.0) + ((RT == 4 && waves > 8) ? 0.43 : 0.0);
 }
 
-// The resident plan's column step: one row per workgroup, S waves each, issue-bound per SIMD (0.42 / 0.65 / 1.10 /
-// 1.30 us at 3 / 7 / 12 / 16 waves on a CU, 0.62 / 1.13 at 6 / 14); more rows than fit run in rounds.
+// Rows per workgroup of the resident plan: the rows of a workgroup share every column load, and the CU's vector-memory
+// pipe is what bounds that kernel -- so as many as still leave one workgroup for every CU (fewer workgroups than CUs
+// would idle whole CUs: a step costs the same however few rows the chip holds), within the register budget.
+int resident_rows_per_wg(int64_t Ng, int S, int cus)
+{
+    if (S <= 1) return 1;                                  // one-segment rows run on the wave kernel
+    const int force = env_int("GPFQ_RESIDENT_RT", 0);
+    const int cap = resident_max_rt(S);
+    for (int rt = 4; rt >= 2; rt >>= 1)
+        if (rt <= cap && (force ? rt == force : (Ng + rt - 1) / rt >= cus)) return rt;
+    return 1;
+}
+
+// The resident plan's column step in microseconds (MI355X, measured: 0.42 / 0.63 / 1.10 at 3 / 7 / 12 segments with one
+// row per workgroup and one workgroup per CU; 0.57 / 0.84 at 3 / 7 segments with two rows): a fixed chain (reduction,
+// divisions, quantizer), ~57 ns of the CU's vector-memory pipe per segment (8 KB of columns) of every workgroup on the
+// CU, and a sweep per further row.  The kernels take their whole register budget (256 / 168 / 128 VGPRs at <= 8 / 12 /
+// 16 waves), so a CU holds 8 / 12 / 16 waves of them; more workgroups than fit run in rounds.
 double resident_step_cost(int64_t Ng, int S, int cus)
 {
-    const int fit = 16 / S > 0 ? 16 / S : 1;                       // workgroups of S waves that fit a CU's 16 wave slots
-    int64_t per_cu = (Ng + cus - 1) / cus;
+    const int RT = resident_rows_per_wg(Ng, S, cus);
+    const int slots = S <= 8 ? 8 : (S <= 12 ? 12 : 16);
+    const int fit = slots / S > 0 ? slots / S : 1;
+    const int64_t tiles = (Ng + RT - 1) / RT;
+    const int64_t per_cu = (tiles + cus - 1) / cus;
     const int conc = (int)(per_cu < fit ? per_cu : fit);
-    const int64_t rounds = (Ng + (int64_t)cus * conc - 1) / ((int64_t)cus * conc);
-    return (double)rounds * (0.22 + 0.072 * conc * S);
+    const int64_t rounds = (tiles + (int64_t)cus * conc - 1) / ((int64_t)cus * conc);
+    const double segs = conc * S;                          // segments whose columns the CU pulls per step
+    const double pipe = segs <= 8 ? 0.057 * segs : 0.057 * 8 + 0.085 * (segs - 8);   // (steeper once every SIMD holds 3+ waves)
+    return (double)rounds * (0.25 + pipe + 0.18 * (RT - 1));
 }
 
 // Cooperative configuration: cheapest modelled step among the (RT, C) pairs whose grid is co-resident.
@@ -193,11 +215,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     if (requested == GPFQ_PLAN_RESIDENT || (requested == GPFQ_PLAN_AUTO && pl.S <= kMaxResidentSegments)) {
         pl.kind = GPFQ_PLAN_RESIDENT;
         pl.waves = pl.S;
-        // one row per workgroup.  (A two-row variant, sharing the column registers between rows, was 6 % faster for
-        // N = 512, m = 7168 -- two one-row workgroups per CU pull every column twice through the CU's L2 port -- but
-        // LLVM kept answering small source changes with copies of its in-flight column registers, which the build's
-        // ISA check rejects; it was dropped.)
-        pl.RT = 1;
+        pl.RT = resident_rows_per_wg(Ng, pl.S, cus);
         // Long rows of which a CU holds only one at a time run in rounds; four rows per cooperative workgroup can then
         // be cheaper (N = 512, m = 13 312, VGG-16's 512-channel convs at batch 512: 2.39 -> 2.17 us per column).
         if (requested == GPFQ_PLAN_AUTO && groups == 1 && have_scratch && Ng > cus && !env_int("GPFQ_COOP_DISABLE", 0)) {
@@ -320,27 +338,40 @@ int launch_coop_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* sc
     }
 }
 
-template <int MODE, int MAXW>
-int launch_resident_t(const Plan& pl, const gpfq::SlabParams& sp, int groups, hipStream_t st)
+typedef void (*ResidentKernel)(const gpfq::SlabParams);
+
+// the instantiated (rows per workgroup, wave bound) pairs: keep resident_max_rt() in step
+ResidentKernel resident_kernel(int RT, int mode, int maxw)
 {
-    if (pl.waves > MAXW || pl.waves != pl.S) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
-    const size_t shm = sizeof(float) * 2 * (size_t)pl.S;
-    dim3 grid((unsigned)sp.Ng, (unsigned)groups, 1);
-    hipLaunchKernelGGL((gpfq::gpfq_resident_kernel<MODE, MAXW>), grid, dim3((unsigned)(64 * pl.waves)), shm, st, sp);
+#define GPFQ_PICK(RTV, MAXWV)                                                                                         \
+    if (RT == RTV && maxw == MAXWV) {                                                                                 \
+        switch (mode) {                                                                                               \
+        case gpfq::MODE_SOFT: return gpfq::gpfq_resident_rt##RTV##_m1_w##MAXWV;                                       \
+        case gpfq::MODE_HARD: return gpfq::gpfq_resident_rt##RTV##_m2_w##MAXWV;                                       \
+        case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_resident_rt##RTV##_m3_w##MAXWV;                                 \
+        default: return gpfq::gpfq_resident_rt##RTV##_m0_w##MAXWV;                                                    \
+        }                                                                                                             \
+    }
+    GPFQ_PICK(1, 8) GPFQ_PICK(2, 8) GPFQ_PICK(4, 8) GPFQ_PICK(1, 12) GPFQ_PICK(2, 12) GPFQ_PICK(1, 16)
+#undef GPFQ_PICK
+    return nullptr;
+}
+
+// most rows per workgroup the register budget of a wave bound leaves room for (the window takes 80 of it)
+int resident_max_rt(int waves) { return waves <= 8 ? 4 : (waves <= 12 ? 2 : 1); }
+
+int launch_resident(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, hipStream_t st)
+{
+    if (pl.waves != pl.S || pl.S > 16) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
+    const int maxw = pl.waves <= 8 ? 8 : (pl.waves <= 12 ? 12 : 16);
+    ResidentKernel k = resident_kernel(pl.RT, mode, maxw);
+    if (!k) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no resident kernel for this (rows, waves) pair");
+    const size_t shm = sizeof(float) * 2 * (size_t)pl.RT * (size_t)pl.S;
+    dim3 grid((unsigned)((sp.Ng + pl.RT - 1) / pl.RT), (unsigned)groups, 1);
+    hipLaunchKernelGGL(k, grid, dim3((unsigned)(64 * pl.waves)), shm, st, sp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ resident kernel launch");
     return GPFQ_OK;
-}
-
-template <int MAXW>
-int launch_resident_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, hipStream_t st)
-{
-    switch (mode) {
-    case gpfq::MODE_SOFT: return launch_resident_t<gpfq::MODE_SOFT, MAXW>(pl, sp, groups, st);
-    case gpfq::MODE_HARD: return launch_resident_t<gpfq::MODE_HARD, MAXW>(pl, sp, groups, st);
-    case gpfq::MODE_STOCHASTIC: return launch_resident_t<gpfq::MODE_STOCHASTIC, MAXW>(pl, sp, groups, st);
-    default: return launch_resident_t<gpfq::MODE_MSQ, MAXW>(pl, sp, groups, st);
-    }
 }
 
 // Launch of the register-resident plans ("slab" = the RT x n block of U a workgroup keeps in registers): the
@@ -375,11 +406,7 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
         if (e != hipSuccess) return hip_fail(e, "GPFQ wave kernel launch");
         return GPFQ_OK;
     }
-    if (pl.kind == GPFQ_PLAN_RESIDENT) {
-        if (pl.waves <= 8) return launch_resident_m<8>(pl, sp, m, groups, st);
-        if (pl.waves <= 12) return launch_resident_m<12>(pl, sp, m, groups, st);
-        return launch_resident_m<16>(pl, sp, m, groups, st);
-    }
+    if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_resident(pl, sp, m, groups, st);
     // the last template argument is the look-ahead of the column loads: two steps wherever the five column
     // buffers fit the variant's register budget
     if (pl.RT == 1) return launch_coop_m<1, 12, 2>(pl, sp, m, scratch, st);

@@ -404,6 +404,101 @@ __device__ __forceinline__ float sweep16(float (&u)[16], const Col16& xp, const 
     return acc;
 }
 
+// ---- the column window: physical registers the compiler never sees --------------------------------------------
+// The register-resident kernels keep five column buffers (x_{t-1}, x_t, x_{t+1} rotating through three, a_t, a_{t+1}
+// through two; 16 fp32 per lane each) with the loads of column t+2 in flight across a whole step.  A register whose
+// load is in flight must not be read, copied, spilt or reused by anything -- which cannot be promised for a value the
+// compiler allocates (it answers register pressure with live-range splits, i.e. copies).  So the five buffers are
+// not C++ values at all: they are the TOP registers of the kernel's budget, v[WB ...], touched only by the asm
+// statements below -- and so are the residual rows themselves (16 registers per row behind the 80 of the columns),
+// which are updated in place for d steps: as C++ values every unrolled step would get a fresh set of them, and copies.  The kernel is declared with amdgpu_num_vgpr(WB), which makes every register from WB up RESERVED
+// for the compiler (it allocates nothing there -- by construction, not by luck), and one empty asm with the last
+// register of the budget on its clobber list makes the kernel descriptor allocate the whole budget.
+// tools/check_async_loads.py verifies on the ISA of every build that no instruction outside these asm statements
+// names a window register and that every sweep is preceded by a wait that covers its columns.
+// All statements are `asm volatile`: they keep their program order among themselves, which is the only ordering the
+// window needs (loads -> wait -> sweep); everything the compiler sees (residual rows, sums) is ordinary data flow.
+//
+// B = first register of a buffer, Q = quarter (4 of the 16 elements: one 16-byte load per lane).
+template <int B, int Q>
+__device__ __forceinline__ void win_load4(const float* base, unsigned lane_off)
+{
+    asm volatile("global_load_dwordx4 v[%c2+%c3:%c2+%c3+3], %0, %1 offset:%c4"
+                 :: "v"(lane_off), "s"(base), "n"(B), "n"(4 * Q), "n"(1024 * Q));
+}
+template <int B>
+__device__ __forceinline__ void win_load16(const float* base, unsigned lane_off)
+{
+    win_load4<B, 0>(base, lane_off);
+    win_load4<B, 1>(base, lane_off);
+    win_load4<B, 2>(base, lane_off);
+    win_load4<B, 3>(base, lane_off);
+}
+template <int B>
+__device__ __forceinline__ void win_zero16()
+{
+#define GPFQ_Z(e) "v_mov_b32 v[%c0+" #e "], 0\n\t"
+    asm volatile(GPFQ_Z(0) GPFQ_Z(1) GPFQ_Z(2) GPFQ_Z(3) GPFQ_Z(4) GPFQ_Z(5) GPFQ_Z(6) GPFQ_Z(7) GPFQ_Z(8) GPFQ_Z(9) GPFQ_Z(10)
+                 GPFQ_Z(11) GPFQ_Z(12) GPFQ_Z(13) GPFQ_Z(14) GPFQ_Z(15) "s_nop 0" :: "n"(B));
+#undef GPFQ_Z
+}
+// wait until at most N of this wave's vector-memory operations are outstanding (they retire in order)
+template <int N>
+__device__ __forceinline__ void win_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+// sweep16 of one residual row against window buffers: U = the row's 16 residual registers (in the window too: the
+// residual is updated in place for d steps, and a value the compiler allocates would be a fresh set of registers --
+// and sixteen copies -- per unrolled step), XP = x_{t-1}, A = a_t, X = x_t.  The same five individually rounded
+// fp32 operations per element, in the same order, as sweep16<true>() above:
+//   p = q*xp; u = u - p; pa = w*a; u = u + pa; acc = fma(u, x, acc)           (step_algorithm.py:148, :141, :144)
+// Ends with s_nop 1: the consumer of acc is a DPP add, and hipcc pads nothing for a producer inside an asm statement.
+// Packed forms for the elementwise part (two elements per instruction; each half is an individually rounded fp32
+// operation, and u + (-p) is u - p exactly): what hipcc itself emits for sweep16 -- 48 instructions per row instead
+// of 80, which matters because a wave issues one vector instruction per 4 cycles however idle its SIMD is.
+// {q, w} travel as ONE register pair; op_sel broadcasts its low half (q) or its high half (w) to both lanes of the pack.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int U, int XP, int A, int X>
+__device__ __forceinline__ float win_sweep16(float q, float w)
+{
+    float acc;
+    v2f t0, t1;
+    const v2f qw = {q, w};
+#define GPFQ_S(e, e1)                                                                                  \
+    "v_pk_mul_f32 %1, %3, v[%c5+" #e ":%c5+" #e1 "] op_sel_hi:[0,1]\n\t"                                \
+    "v_pk_mul_f32 %2, %3, v[%c6+" #e ":%c6+" #e1 "] op_sel:[1,0]\n\t"                                   \
+    "v_pk_add_f32 v[%c4+" #e ":%c4+" #e1 "], v[%c4+" #e ":%c4+" #e1 "], %1 neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+    "v_pk_add_f32 v[%c4+" #e ":%c4+" #e1 "], v[%c4+" #e ":%c4+" #e1 "], %2\n\t"                           \
+    "v_fmac_f32 %0, v[%c4+" #e "], v[%c7+" #e "]\n\t"                                                   \
+    "v_fmac_f32 %0, v[%c4+" #e1 "], v[%c7+" #e1 "]\n\t"
+    asm volatile("v_mov_b32 %0, 0\n\t"
+                 GPFQ_S(0, 1) GPFQ_S(2, 3) GPFQ_S(4, 5) GPFQ_S(6, 7) GPFQ_S(8, 9) GPFQ_S(10, 11) GPFQ_S(12, 13) GPFQ_S(14, 15)
+                 "s_nop 1"
+                 : "=&v"(acc), "=&v"(t0), "=&v"(t1)
+                 : "v"(qw), "n"(U), "n"(XP), "n"(A), "n"(X));
+#undef GPFQ_S
+    return acc;
+}
+// the pending subtraction of the last step, in place: u = u - q * x_{d-1}                          (step_algorithm.py:148)
+template <int U, int XL>
+__device__ __forceinline__ void win_final_sub16(float q)
+{
+    float t;
+#define GPFQ_F(e) "v_mul_f32 %0, %1, v[%c3+" #e "]\n\tv_sub_f32 v[%c2+" #e "], v[%c2+" #e "], %0\n\t"
+    asm volatile(GPFQ_F(0) GPFQ_F(1) GPFQ_F(2) GPFQ_F(3) GPFQ_F(4) GPFQ_F(5) GPFQ_F(6) GPFQ_F(7) GPFQ_F(8) GPFQ_F(9) GPFQ_F(10)
+                 GPFQ_F(11) GPFQ_F(12) GPFQ_F(13) GPFQ_F(14) GPFQ_F(15) "s_nop 0"
+                 : "=&v"(t) : "v"(q), "n"(U), "n"(XL));
+#undef GPFQ_F
+}
+// four consecutive window registers into ordinary ones
+template <int B>
+__device__ __forceinline__ void win_read4(float (&d)[4])
+{
+    asm volatile("v_mov_b32 %0, v[%c4+0]\n\tv_mov_b32 %1, v[%c4+1]\n\tv_mov_b32 %2, v[%c4+2]\n\tv_mov_b32 %3, v[%c4+3]\n\ts_nop 0"
+                 : "=v"(d[0]), "=v"(d[1]), "=v"(d[2]), "=v"(d[3]) : "n"(B));
+}
+
 __device__ __forceinline__ const float* uniform_ptr(const float* p)
 {
     const uintptr_t v = reinterpret_cast<uintptr_t>(p);

@@ -5,6 +5,7 @@
 // are independent, and per step a workgroup makes ONE pass over its rows, fusing
 //   u -= q_{t-1} x_{t-1};  u += w_t a_t;  <u, x_t>.
 #pragma once
+#include <type_traits>
 #include "gpfq_device.h"
 
 namespace gpfq {
@@ -452,88 +453,191 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-// Resident plan (a whole row in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE
-// barrier per step.  Every wave leaves its segment sum in LDS, and behind the barrier every wave finishes the slot
+// Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE
+// barrier per step.  Every wave leaves its segment sums in LDS, and behind the barrier every wave finishes the slot
 // tree, divides and quantizes for itself (the same bits in every wave), so q never travels through LDS and there
-// is no second barrier.  The column loads run two steps ahead as in gpfq_coop_kernel (DEPTH 2), two requests at a
-// time at four points of the step: eight at once from every wave fill the CU's vector-memory queue, and a wave
-// whose request is not accepted stalls right there, on the critical path.  The step is a dependent chain of ~1000
-// cycles, so it is also kept free of taken branches (each ~20 cycles): no level tests in the slot tree, no
-// "is there a next column" test, the rare Q / idx flush out of line.
-// One row per workgroup: RT is a template parameter only for the helpers it shares with the cooperative kernel.
+// is no second barrier.
+//
+// RT rows per workgroup share the column registers.  What bounds this kernel is the CU's vector-memory pipe: a wave's
+// 16-byte-per-lane load moves 1 KB in ~16 clocks, so the 8 KB a segment needs per step (x_t and a_t) cost ~53 ns of
+// the pipe whatever else happens (measured: 0.42 / 0.65 / 1.10 us per step at 3 / 7 / 12 segments, and exactly twice
+// that with two one-row workgroups on a CU; 22 TB/s of L2 -> CU column traffic chip-wide on every shape).  Two rows
+// in one workgroup pull each column ONCE: half the pipe time per row.
+//
+// The five column buffers live in the column window (gpfq_device.h: physical registers reserved from the compiler),
+// x_t in X[t % 3], a_t in A[t % 2], a six-fold unrolled loop naming them; the loads run two steps ahead, two requests
+// at a time at four points of the step (eight at once from every wave fill the CU's vector-memory queue, and a wave
+// whose request is not accepted stalls right there, on the critical path).  The step is a dependent chain of ~1000
+// cycles, so it is also kept free of taken branches (each ~20 cycles): no level tests in the slot tree, no "is there
+// a next column" test, the rare Q / idx flush out of line.
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int MAXW>
-__global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabParams p)
+// Tail of the window kernels for one row: the pending subtraction of the last step (in place, in the window), then the
+// residual leaves the registers four elements at a time (step_algorithm.py:148), with the fused sum of squares.
+template <int U, int XL>
+__device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, bool valid, int64_t grow, int64_t kbase, int seg, int lane)
 {
-    constexpr int RT = 1;
-    extern __shared__ float smem[];                 // seg[2][S]
+    win_final_sub16<U, XL>(qlast);
+    if (!valid) return;
+    float* Urow = p.U + grow * p.ldu;
+    float acc = 0.0f;
+    auto chunk = [&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        float v[4];
+        win_read4<U + 4 * c>(v);
+        const int64_t k0 = kbase + 256 * c;
+        if (p.vec && k0 + 3 < p.m) {
+            *reinterpret_cast<float4*>(Urow + k0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < p.m) Urow[k0 + j] = v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(v[j], v[j], acc);       // element order e = 4c + j, as store_segment_sumsq
+    };
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});
+    chunk(std::integral_constant<int, 2>{});
+    chunk(std::integral_constant<int, 3>{});
+    if (p.usq) {
+        const float sg = wave_tree64_lane63(acc);
+        if (lane == 63) p.usq[grow * p.S + seg] = sg;
+    }
+}
+
+// WB = first register of the window = the kernel's register budget minus 80 + 16 RT (see GPFQ_DEFINE_RESIDENT below):
+// three x buffers, two a buffers, then the RT residual rows.
+template <int RT, int MODE, int WB>
+__device__ __forceinline__ void resident_body(const SlabParams& p)
+{
+    static_assert(RT == 1 || RT == 2 || RT == 4, "one DPP row of 16 lanes per residual row");
+    constexpr int X0 = WB, X1 = WB + 16, X2 = WB + 32, A0 = WB + 48, A1 = WB + 64, U0 = WB + 80;
+    extern __shared__ float smem[];                 // seg[2][RT][S]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int S = p.S;                              // == waves of the workgroup
-    const int P = pow2_ceil(S);                     // slots of the canonical tree, <= 16: one DPP row
-    const int row = blockIdx.x, g = blockIdx.y;
-    const SlotMap smap = make_slot_map(S, P, 0, 1, lane % P, P);
-    const bool occupied = (smap.mask & 1u) && lane < P;          // lanes >= P contribute +0.0f
-    const int64_t grow = (int64_t)g * p.Ng + row;
+    const int P = pow2_ceil(S);                     // slots of the canonical tree, <= 16: one DPP row per residual row
+    const int row0 = blockIdx.x * RT, g = blockIdx.y;
+    const SlotMap smap = make_slot_map(S, P, 0, 1, (lane & 15) % P, P);
+    const int r16 = lane >> 4;                      // the residual row this lane serves in the slot tree
+    const bool occupied = (smap.mask & 1u) && (lane & 15) < P && r16 < RT;   // other lanes contribute +0.0f
+    const int seg_off = (r16 < RT ? r16 : 0) * S + smap.s0;                  // a valid LDS word in every lane
+    const int64_t grow0 = (int64_t)g * p.Ng + row0;
     const int64_t kbase = (int64_t)wave * kSeg + 4 * lane;
     const float* xload = uniform_ptr(p.XT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const float* aload = uniform_ptr(p.AT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const unsigned lane_off = 16u * (unsigned)lane;
     const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
-    const kfloat* wrow = as_scalar(p.W + grow * p.ldw);
     // "this is wave 0" as a scalar, so that the flush test of the Q / idx history is a scalar branch
     const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
 
-    float u[RT][16];
+    const kfloat* wrow[RT];
+    float qprev[RT], wcur[RT], qhist[RT];
+    int ihist[RT];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) u[0][e] = 0.0f;
-    float qprev[RT] = {0.0f}, wcur = wrow[0], n2cur = nrm[0];
-    float qhist = 0.0f;
-    int ihist = 0;
+    for (int r = 0; r < RT; ++r) {
+        // rows past the end of the group repeat its last row (computed, never stored)
+        const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
+        wrow[r] = as_scalar(p.W + gr * p.ldw);
+        qprev[r] = 0.0f;
+        wcur[r] = wrow[r][0];
+        qhist[r] = 0.0f;
+        ihist[r] = 0;
+    }
+    float n2cur = nrm[0];
 
-    // x_t lives in X[t % 3], a_t in A[t % 2]; X2 starts as x_{-1} = 0 (q_{-1} = 0)
-    Col16 X0, X1, X2, A0, A1;
-    zero16(X2);
-    load16_async(X0, xload, lane_off);
-    load16_async(A0, aload, lane_off);
+    // the residual starts at 0 (a non-zero initial residual is the streaming plan's job); x_t lives in X[t % 3],
+    // a_t in A[t % 2]; X2 starts as x_{-1} = 0 (q_{-1} = 0)
+    win_zero16<U0>();
+    if constexpr (RT >= 2) win_zero16<U0 + 16>();
+    if constexpr (RT >= 4) { win_zero16<U0 + 32>(); win_zero16<U0 + 48>(); }
+    win_zero16<X2>();
+    win_load16<X0>(xload, lane_off);
+    win_load16<A0>(aload, lane_off);
     {
         const int64_t adv = (1 < p.d) ? p.m_pad : 0;   // a one-column layer re-reads column 0
         xload += adv;
         aload += adv;
     }
-    load16_async(X1, xload, lane_off);
-    load16_async(A1, aload, lane_off);
+    win_load16<X1>(xload, lane_off);
+    win_load16<A1>(aload, lane_off);
 
+#ifdef GPFQ_STAMPS
+    // diagnostic build only: cycles per phase of a step, summed by wave 0 and the last wave of block 0 into status[16..]
+    unsigned long long rst_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long rst_prev = 0;
+#define GPFQ_RSTAMP(i)                                                                                  \
+    {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long now_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        rst_sum[i] += now_ - rst_prev;                                                                  \
+        rst_prev = now_;                                                                                \
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rst_prev)::"memory");
+#else
+#define GPFQ_RSTAMP(i)
+#endif
     int t = 0;
-    // one step; xprev = x_{t-1}, xcur = x_t, acur = a_t.  Returns false after the last column.
-    auto step = [&](Col16& xprev, Col16& xcur, Col16& acur) -> bool {
+    // one step; XP holds x_{t-1}, XC x_t, AC a_t.  Returns false after the last column.
+    auto step = [&](auto xp_, auto xc_, auto ac_) -> bool {
+        constexpr int XP = decltype(xp_)::value, XC = decltype(xc_)::value, AC = decltype(ac_)::value;
+        GPFQ_RSTAMP(0)
         const bool more = t + 1 < p.d;
-        float* seg = smem + (t & 1) * S;
-        // next column's weight and norm through the scalar cache; the last step re-reads its own (unused) pair
-        const int tn = more ? t + 1 : t;
-        const float wn = wrow[tn], n2n = nrm[tn];
-        wait_landed<8>(xcur, acur);                 // column t; the eight loads of column t+1 stay in flight
-        const float acc = sweep16<true>(u[0], xprev, acur, xcur, qprev[0], wcur);
-        // column t+2 goes into the registers the sweep has just finished with (x_{t-1}'s and a_t's); the last two
+        float* seg = smem + (t & 1) * RT * S;
+        win_wait<8>();                              // column t has landed; the eight loads of column t+1 stay in flight
+        GPFQ_RSTAMP(1)
+        float acc[RT];
+        acc[0] = win_sweep16<U0, XP, AC, XC>(qprev[0], wcur[0]);
+        if constexpr (RT >= 2) acc[1] = win_sweep16<U0 + 16, XP, AC, XC>(qprev[1], wcur[1]);
+        if constexpr (RT >= 4) {
+            acc[2] = win_sweep16<U0 + 32, XP, AC, XC>(qprev[2], wcur[2]);
+            acc[3] = win_sweep16<U0 + 48, XP, AC, XC>(qprev[3], wcur[3]);
+        }
+        GPFQ_RSTAMP(2)
+        // column t+2 goes into the registers the sweeps have just finished with (x_{t-1}'s and a_t's); the last two
         // steps re-read the last column rather than branch
         {
             const int64_t adv = (t + 2 < p.d) ? p.m_pad : 0;
             xload += adv;
             aload += adv;
         }
-        load4_async<0>(xprev, xload, lane_off);
-        load4_async<0>(acur, aload, lane_off);
-        const float sg = wave_tree64_lane63(acc);
-        if (lane == 63) seg[wave] = sg;
+        win_load4<XP, 0>(xload, lane_off);
+        win_load4<AC, 0>(aload, lane_off);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float sg = wave_tree64_lane63(acc[r]);
+            if (lane == 63) seg[r * S + wave] = sg;
+        }
         float uni = 0.0f;
-        if (MODE == MODE_STOCHASTIC) uni = philox_uniform(p.seed, p.row_id0 + (uint64_t)grow, (uint64_t)t);
-        load4_async<1>(xprev, xload, lane_off);
-        load4_async<1>(acur, aload, lane_off);
+        if (MODE == MODE_STOCHASTIC)
+            uni = philox_uniform(p.seed, p.row_id0 + (uint64_t)(grow0 + ((r16 < RT && row0 + r16 < p.Ng) ? r16 : 0)), (uint64_t)t);
+        win_load4<XP, 1>(xload, lane_off);
+        win_load4<AC, 1>(aload, lane_off);
+        GPFQ_RSTAMP(3)
         __syncthreads();
-        load4_async<2>(xprev, xload, lane_off);
-        load4_async<2>(acur, aload, lane_off);
-        // the slot tree in every wave: lane = slot; lanes >= P hold +0.0f, so the four levels need no tests
-        const float val = seg[smap.s0];             // s0 is a valid segment in every lane
+        GPFQ_RSTAMP(4)
+        win_load4<XP, 2>(xload, lane_off);
+        win_load4<AC, 2>(aload, lane_off);
+        // the slot tree in every wave, all RT rows at once: lane = 16 * row + slot; the other lanes hold +0.0f, so the
+        // four levels need no tests
+        const float val = seg[seg_off];
         const float v = wave_tree16_zero_padded(occupied ? val : 0.0f);
+        // Next column's weights and norm through the scalar cache (the last step re-reads its own, unused, ones rather
+        // than branch) -- requested HERE, behind the LDS read: scalar loads and LDS share one counter (lgkmcnt) and
+        // return out of order, so every wait on that counter is a wait for all of them; requested at the top of the
+        // step they made the `s_waitcnt lgkmcnt(0)` in front of the sweep wait a whole scalar-cache round trip.  From
+        // here the next wait on the counter is a full quantizer away.  The scheduling barrier keeps the tree above, the
+        // opaque asm (its result is the address) keeps the requests below.
+        int tn = more ? t + 1 : t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(tn)::"memory");
+        tn = __builtin_amdgcn_readfirstlane(tn);    // (an asm result counts as divergent; this makes it scalar again)
+        float wn[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
+        const float n2n = nrm[tn];
+        __builtin_amdgcn_sched_barrier(0);          // ... and keeps them from sinking below the divisions
         const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
         int id;
         float q;
@@ -541,45 +645,97 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_resident_kernel(const SlabPara
         else if (MODE == MODE_HARD) q = quant_hard(p.step, sarg, p.Kf, p.lamb, id);
         else if (MODE == MODE_STOCHASTIC) q = quant_stochastic(p.step, sarg, p.Kf, uni, id);
         else q = quant_msq(p.step, sarg, p.Kf, id);
-        qprev[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), 0));
-        const int idr = __builtin_amdgcn_readlane(id, 0);
         // Q / idx: 64 steps of history in registers (lane l holds step t0 + l), one coalesced store every 64 steps
-        if (lane == (t & 63)) { qhist = qprev[0]; ihist = idr; }
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), 16 * r));
+#ifdef GPFQ_STAMPS
+            if (r == RT - 1) GPFQ_RSTAMP(5)
+#endif
+            const int idr = __builtin_amdgcn_readlane(id, 16 * r);
+            if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+        }
         if (__builtin_expect(((t & 63) == 63 || !more) && wave0, 0)) {
             const int t0 = t & ~63;
             if (lane <= t - t0) {
-                p.Q[grow * p.ldq + t0 + lane] = qhist;
-                if (p.idx) {
-                    if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[grow * p.ldi + t0 + lane] = (int8_t)ihist;
-                    else reinterpret_cast<int16_t*>(p.idx)[grow * p.ldi + t0 + lane] = (int16_t)ihist;
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    if (row0 + r < p.Ng) {
+                        const int64_t gw = grow0 + r;
+                        p.Q[gw * p.ldq + t0 + lane] = qhist[r];
+                        if (p.idx) {
+                            if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)ihist[r];
+                            else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)ihist[r];
+                        }
+                    }
                 }
             }
         }
-        load4_async<3>(xprev, xload, lane_off);
-        load4_async<3>(acur, aload, lane_off);
+        win_load4<XP, 3>(xload, lane_off);
+        win_load4<AC, 3>(aload, lane_off);
         if (!more) return false;
-        wcur = wn;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
         ++t;
         return true;
     };
+    using I0 = std::integral_constant<int, X0>; using I1 = std::integral_constant<int, X1>; using I2 = std::integral_constant<int, X2>;
+    using J0 = std::integral_constant<int, A0>; using J1 = std::integral_constant<int, A1>;
     int k = 0;                                       // buffer that holds x_t when the loop ends (t % 3)
     for (;;) {
-        k = 0; if (!step(X2, X0, A0)) break;
-        k = 1; if (!step(X0, X1, A1)) break;
-        k = 2; if (!step(X1, X2, A0)) break;
-        k = 0; if (!step(X2, X0, A1)) break;
-        k = 1; if (!step(X0, X1, A0)) break;
-        k = 2; if (!step(X1, X2, A1)) break;
+        k = 0; if (!step(I2{}, I0{}, J0{})) break;
+        k = 1; if (!step(I0{}, I1{}, J1{})) break;
+        k = 2; if (!step(I1{}, I2{}, J0{})) break;
+        k = 0; if (!step(I2{}, I0{}, J1{})) break;
+        k = 1; if (!step(I0{}, I1{}, J0{})) break;
+        k = 2; if (!step(I1{}, I2{}, J1{})) break;
     }
-    // every load issued above has landed before the buffers are looked at again
-    wait_landed<0>(X0, X1);
-    wait_landed<0>(X2, A0);
-    wait_landed<0>(A1);
-    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row, grow, kbase, wave, lane);
-    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row, grow, kbase, wave, lane);
-    else finish_rows<RT>(p, u, qprev, X2, row, grow, kbase, wave, lane);
+#ifdef GPFQ_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == S - 1) && p.status) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 16) + (wave == 0 ? 0 : 8);
+        for (int i = 0; i < 8; ++i) dbg[i] = rst_sum[i];
+    }
+#endif
+    // every load issued above has landed before the last column is used again
+    win_wait<0>();
+    auto finish = [&](auto xl_) {
+        constexpr int XL = decltype(xl_)::value;
+        finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, kbase, wave, lane);
+        if constexpr (RT >= 2) finish_row_w<U0 + 16, XL>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, kbase, wave, lane);
+        if constexpr (RT >= 4) {
+            finish_row_w<U0 + 32, XL>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, kbase, wave, lane);
+            finish_row_w<U0 + 48, XL>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, kbase, wave, lane);
+        }
+    };
+    if (k == 0) finish(I0{});
+    else if (k == 1) finish(I1{});
+    else finish(I2{});
 }
+
+// One __global__ per (rows per workgroup, quantizer, wave bound): amdgpu_num_vgpr takes a literal, and it is what
+// reserves the window -- WB = budget(MAXW) - 80 - 16 RT registers for the compiler, the rest for the window.  On
+// gfx950 (one register file for VGPRs and AGPRs) amdgpu_num_vgpr(n) leaves the compiler 2n registers, v0 .. v(2n-1)
+// (probe: a kernel that needs 200 registers uses v0..v143 and spills the rest under amdgpu_num_vgpr(72)), hence
+// WB / 2; the build's ISA check (tools/check_async_loads.py: no compiler instruction may name a window register) is
+// what guarantees it for every kernel of every build.
+// MAXW = most waves the kernel may be launched with: 8 -> 256 VGPRs, 12 -> 168, 16 -> 128.
+#define GPFQ_DEFINE_RESIDENT(RT, MODE, MAXW, WB, LAST)                                                            \
+    __global__ void __launch_bounds__(64 * MAXW) __attribute__((amdgpu_num_vgpr(WB / 2)))                          \
+    gpfq_resident_rt##RT##_m##MODE##_w##MAXW(const SlabParams p)                                                 \
+    {                                                                                                             \
+        asm volatile("" ::: LAST);      /* makes the kernel descriptor allocate the whole budget */               \
+        resident_body<RT, MODE, WB>(p);                                                                           \
+    }
+#define GPFQ_DEFINE_RESIDENT_MODES(RT, MAXW, WB, LAST)                                                            \
+    GPFQ_DEFINE_RESIDENT(RT, 0, MAXW, WB, LAST) GPFQ_DEFINE_RESIDENT(RT, 1, MAXW, WB, LAST)                       \
+    GPFQ_DEFINE_RESIDENT(RT, 2, MAXW, WB, LAST) GPFQ_DEFINE_RESIDENT(RT, 3, MAXW, WB, LAST)
+GPFQ_DEFINE_RESIDENT_MODES(1, 8, 160, "v255")
+GPFQ_DEFINE_RESIDENT_MODES(2, 8, 144, "v255")
+GPFQ_DEFINE_RESIDENT_MODES(4, 8, 112, "v255")
+GPFQ_DEFINE_RESIDENT_MODES(1, 12, 72, "v167")
+GPFQ_DEFINE_RESIDENT_MODES(2, 12, 56, "v167")
+GPFQ_DEFINE_RESIDENT_MODES(1, 16, 32, "v127")
 
 // ------------------------------------------------------------------------------------------------
 // Streaming plan: any (N, m).  The residual rows stay in the caller's U (HBM / L2 / Infinity Cache) and

@@ -26,22 +26,66 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT = os.path.join(ROOT, "quantized_neural_nets_amd", "csrc", "build", "gpfq_capi-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
+def _sum(expr):
+    """'176+4+3' -> 183 (the column-window statements write register numbers as base+offset sums)"""
+    return sum(int(x) for x in expr.split("+"))
+
+
 def regs_of(tok):
-    """v12 -> {12}; v[4:7] -> {4,5,6,7}; anything else -> {}"""
+    """v12 -> {12}; v[4:7] -> {4,5,6,7}; v[176+4:176+4+3] -> {180..183}; v[176+2] -> {178}; anything else -> {}"""
     m = re.fullmatch(r"v(\d+)", tok)
     if m:
         return {int(m.group(1))}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    m = re.fullmatch(r"v\[([\d+]+):([\d+]+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        return set(range(_sum(m.group(1)), _sum(m.group(2)) + 1))
+    m = re.fullmatch(r"v\[([\d+]+)\]", tok)
+    if m:
+        return {_sum(m.group(1))}
     return set()
 
 
 def vregs(line):
     body = line.split(";")[0]
     out = set()
-    for tok in re.findall(r"v\[\d+:\d+\]|\bv\d+\b", body):
+    for tok in re.findall(r"v\[[\d+]+(?::[\d+]+)?\]|\bv\d+\b", body):
         out |= regs_of(tok)
+    return out
+
+
+def window_violations(name, lines):
+    """Kernels that keep their column buffers in a reserved register window (gpfq_device.h win_*): the window is
+    everything from the lowest destination of an asm load upwards, and NO instruction outside an asm statement may
+    name a register in it -- the compiler must not know those registers exist."""
+    lo = None
+    in_asm = False
+    for ln in lines:
+        st = ln.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif st.startswith(";;#ASMEND"):
+            in_asm = False
+        elif in_asm and st.startswith("global_load_dwordx4") and "+" in st.split()[1]:
+            r = regs_of(st.split()[1].rstrip(","))
+            lo = min(r) if lo is None else min(lo, min(r))
+    if lo is None:
+        return []
+    out = []
+    in_asm = False
+    for no, ln in enumerate(lines):
+        st = ln.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if st.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if in_asm or not st or st.startswith((";", ".")) or st.endswith(":"):
+            continue
+        hit = [r for r in vregs(st) if r >= lo]
+        if hit:
+            out.append("%s: line %d: compiler code names column-window register(s) %s (window starts at v%d): %s" % (
+                name, no, sorted(hit), lo, st))
     return out
 
 
@@ -99,6 +143,7 @@ def check_kernel(name, lines):
     again = []
     replay(name, lines, inflight, again, True)
     problems += [p for p in again if p not in seen and "loads into register(s) still in flight" not in p]
+    problems += window_violations(name, lines)
     return True, problems
 
 
@@ -108,7 +153,7 @@ def main():
     kernels = {}
     cur = None
     for ln in text:
-        m = re.match(r"^(_ZN4gpfq\w+):", ln)
+        m = re.match(r"^(_ZN4gpfq\w+|gpfq_\w+):", ln)
         if m:
             cur = m.group(1)
             kernels[cur] = []

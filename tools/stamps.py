@@ -22,7 +22,11 @@ for a in sys.argv[1:]:
     torch.cuda.synchronize()
     scr = _lib.scratch(dev)
     dbg = scr[96 * 1024 + 64: 96 * 1024 + 64 + 128].view(torch.int64).cpu().tolist()
-    print(a, _lib.describe_plan(N, dl, m))
+    desc = _lib.describe_plan(N, dl, m)
+    print(a, desc)
+    if desc.startswith("resident"):
+        names = ["loop bookkeeping, last quarter of the loads, history", "wait for column t (vmcnt)", "sweeps", "first quarter of the loads, lane trees, LDS write, second quarter",
+                 "barrier", "third quarter, LDS read, slot tree, divisions, quantizer, readlanes", "-", "-"]
     for w, off in (("wave0", 0), ("lastwave", 8)):
         tot = sum(dbg[off:off + 8])
         print("  %-8s total %.0f cyc/step:" % (w, tot / dl), "  ".join("%s %.0f" % (names[i], dbg[off + i] / dl) for i in range(8)))
