@@ -157,7 +157,7 @@ def kernel_name(desc, mode=0):
             return "gpfq_wave_kernel<"
         return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
-        return "gpfq_coop_kernel<%d, %d, %d" % (rt, mode, 8 if waves <= 8 else 12)
+        return "gpfq_coop_rt%d_m%d_w%d" % (rt, mode, 12 if (rt == 1 or waves > 8) else 8)
     return "gpfq_stream_kernel<%d, true" % rt
 
 

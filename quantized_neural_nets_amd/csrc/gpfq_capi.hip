@@ -297,12 +297,41 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     return sp;
 }
 
-template <int RT, int MODE, int MAXW, int DEPTH>
-int launch_coop_t(const Plan& pl, const gpfq::SlabParams& sp, void* scratch, hipStream_t st)
+typedef void (*SlabKernel)(const gpfq::SlabParams);
+
+// the instantiated cooperative (rows per workgroup, wave bound) pairs -- keep slab_max_waves() in step
+SlabKernel coop_kernel(int RT, int mode, int maxw)
 {
-    if (pl.waves > MAXW) return fail(GPFQ_ERR_UNSUPPORTED, "internal: waves exceed the kernel variant's bound");
-    // one more wave for the reducer role when the variant's register budget allows it
-    const int nwaves = pl.waves + ((pl.waves + 1 <= MAXW && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
+#define GPFQ_PICK(RTV, MAXWV)                                                                                         \
+    if (RT == RTV && maxw == MAXWV) {                                                                                 \
+        switch (mode) {                                                                                               \
+        case gpfq::MODE_SOFT: return gpfq::gpfq_coop_rt##RTV##_m1_w##MAXWV;                                           \
+        case gpfq::MODE_HARD: return gpfq::gpfq_coop_rt##RTV##_m2_w##MAXWV;                                           \
+        case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_coop_rt##RTV##_m3_w##MAXWV;                                     \
+        default: return gpfq::gpfq_coop_rt##RTV##_m0_w##MAXWV;                                                        \
+        }                                                                                                             \
+    }
+    GPFQ_PICK(1, 12) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(4, 8)
+#undef GPFQ_PICK
+    if (RT == 4 && maxw == 12) {                    // (no stochastic variant: see GPFQ_DEFINE_COOP in gpfq_loop_kernels.h)
+        switch (mode) {
+        case gpfq::MODE_SOFT: return gpfq::gpfq_coop_rt4_m1_w12;
+        case gpfq::MODE_HARD: return gpfq::gpfq_coop_rt4_m2_w12;
+        case gpfq::MODE_MSQ: return gpfq::gpfq_coop_rt4_m0_w12;
+        default: return nullptr;
+        }
+    }
+    return nullptr;
+}
+
+int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
+{
+    const int RT = pl.RT;
+    const int maxw = (RT == 1 || pl.waves > 8) ? 12 : 8;
+    SlabKernel kern = coop_kernel(RT, mode, maxw);
+    if (!kern || pl.waves > maxw) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
+    // one more wave for the reducer role when the variant's wave bound allows it
+    const int nwaves = pl.waves + ((pl.waves + 1 <= maxw && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
     const int threads = 64 * nwaves;
     const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1) + 2 * RT * 64);
     const int nblocks = pl.tiles * pl.C;
@@ -310,7 +339,7 @@ int launch_coop_t(const Plan& pl, const gpfq::SlabParams& sp, void* scratch, hip
     // known to over-report by one only near the SGPR limit of >= 6 waves per SIMD; these kernels run at
     // <= 4, so the answer is taken as is -- and every spin is bounded anyway)
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gpfq::gpfq_coop_kernel<RT, MODE, MAXW, DEPTH>, threads, shm);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, shm);
     if (e != hipSuccess) return hip_fail(e, "occupancy query");
     const int cus = device_cu_count();
     const int need = (nblocks + cus - 1) / cus;
@@ -321,27 +350,15 @@ int launch_coop_t(const Plan& pl, const gpfq::SlabParams& sp, void* scratch, hip
     if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
     e = hipMemsetAsync(scratch, 0, xbytes, st);
     if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
-    hipLaunchKernelGGL((gpfq::gpfq_coop_kernel<RT, MODE, MAXW, DEPTH>), dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, sp);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, sp);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ cooperative kernel launch");
     return GPFQ_OK;
 }
 
-template <int RT, int MAXW, int DEPTH>
-int launch_coop_m(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
-{
-    switch (mode) {
-    case gpfq::MODE_SOFT: return launch_coop_t<RT, gpfq::MODE_SOFT, MAXW, DEPTH>(pl, sp, scratch, st);
-    case gpfq::MODE_HARD: return launch_coop_t<RT, gpfq::MODE_HARD, MAXW, DEPTH>(pl, sp, scratch, st);
-    case gpfq::MODE_STOCHASTIC: return launch_coop_t<RT, gpfq::MODE_STOCHASTIC, MAXW, DEPTH>(pl, sp, scratch, st);
-    default: return launch_coop_t<RT, gpfq::MODE_MSQ, MAXW, DEPTH>(pl, sp, scratch, st);
-    }
-}
-
-typedef void (*ResidentKernel)(const gpfq::SlabParams);
 
 // the instantiated (rows per workgroup, wave bound) pairs: keep resident_max_rt() in step
-ResidentKernel resident_kernel(int RT, int mode, int maxw)
+SlabKernel resident_kernel(int RT, int mode, int maxw)
 {
 #define GPFQ_PICK(RTV, MAXWV)                                                                                         \
     if (RT == RTV && maxw == MAXWV) {                                                                                 \
@@ -364,7 +381,7 @@ int launch_resident(const Plan& pl, const gpfq::SlabParams& sp, int mode, int gr
 {
     if (pl.waves != pl.S || pl.S > 16) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
     const int maxw = pl.waves <= 8 ? 8 : (pl.waves <= 12 ? 12 : 16);
-    ResidentKernel k = resident_kernel(pl.RT, mode, maxw);
+    SlabKernel k = resident_kernel(pl.RT, mode, maxw);
     if (!k) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no resident kernel for this (rows, waves) pair");
     const size_t shm = sizeof(float) * 2 * (size_t)pl.RT * (size_t)pl.S;
     dim3 grid((unsigned)((sp.Ng + pl.RT - 1) / pl.RT), (unsigned)groups, 1);
@@ -407,15 +424,7 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
         return GPFQ_OK;
     }
     if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_resident(pl, sp, m, groups, st);
-    // the last template argument is the look-ahead of the column loads: two steps wherever the five column
-    // buffers fit the variant's register budget
-    if (pl.RT == 1) return launch_coop_m<1, 12, 2>(pl, sp, m, scratch, st);
-    if (pl.RT == 2) {
-        if (pl.waves <= 8) return launch_coop_m<2, 8, 2>(pl, sp, m, scratch, st);
-        return launch_coop_m<2, 12, 2>(pl, sp, m, scratch, st);
-    }
-    if (pl.waves <= 8) return launch_coop_m<4, 8, 2>(pl, sp, m, scratch, st);
-    return launch_coop_m<4, 12, 1>(pl, sp, m, scratch, st);
+    return launch_coop(pl, sp, m, scratch, st);
 }
 
 // most waves per workgroup an instantiation exists for

@@ -207,40 +207,62 @@ __device__ __forceinline__ void store_segment_sumsq(float* usq, int64_t slot, co
     if (lane == 63) usq[slot] = sg;
 }
 
-// Shared tail of the register-resident kernels: the pending subtraction of the last step, then the residual leaves the registers (step_algorithm.py:148).
-template <int RT>
-__device__ __forceinline__ void finish_rows(const SlabParams& p, float (&u)[RT][16], const float (&qprev)[RT], const Col16& xlast,
-                                            int row0, int64_t grow0, int64_t kbase, int seg, int lane)
+// Tail of the window kernels for one row: the pending subtraction of the last step (in place, in the window), then the
+// residual leaves the registers four elements at a time (step_algorithm.py:148), with the fused sum of squares.
+template <int U, int XL>
+__device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, bool valid, int64_t grow, int seg, int lane)
 {
+    win_final_sub16<U, XL>(qlast);
+    if (!valid) return;
+    const int64_t kbase = (int64_t)seg * kSeg + 4 * lane;      // computed here: nothing 64-bit stays live across the loop
+    float* Urow = p.U + grow * p.ldu;
+    float acc = 0.0f;
+    auto chunk = [&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        float v[4];
+        win_read4<U + 4 * c>(v);
+        const int64_t k0 = kbase + 256 * c;
+        if (p.vec && k0 + 3 < p.m) {
+            *reinterpret_cast<float4*>(Urow + k0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < p.m) Urow[k0 + j] = v[j];
+        }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float pq = qprev[r] * xlast.v[e >> 2][e & 3];
-            u[r][e] = u[r][e] - pq;
-        }
-        if (row0 + r < p.Ng) {
-            float* Urow = p.U + (grow0 + r) * p.ldu;
-            if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
-            else store_u16<false>(u[r], Urow, kbase, p.m);
-            if (p.usq) store_segment_sumsq(p.usq, (grow0 + r) * p.S + seg, u[r], lane);
-        }
+        for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(v[j], v[j], acc);       // element order e = 4c + j, as store_segment_sumsq
+    };
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});
+    chunk(std::integral_constant<int, 2>{});
+    chunk(std::integral_constant<int, 3>{});
+    if (p.usq) {
+        const float sg = wave_tree64_lane63(acc);
+        if (lane == 63) p.usq[grow * p.S + seg] = sg;
     }
 }
 
-// MAXW = most waves per workgroup the instantiation may be launched with; it sets the register budget
-// (16 waves -> 128 VGPRs, 12 -> 168, 8 -> 256): more rows per workgroup need the roomier variants.
-// DEPTH = look-ahead of the column loads in steps.  DEPTH 2: three x buffers and two a buffers rotate by name in a
-// six-fold unrolled loop (x_t in X[t % 3], a_t in A[t % 2]), column t+2 is requested behind barrier 2 of step t into
-// the registers sweep t has finished with, and sweep t+1 waits for column t+1 only (vmcnt(8): the eight loads of
-// column t+2 stay in flight).  With 12 waves a workgroup pulls 96 KB of columns per step, which at the ~70 GB/s a
-// CU gets from L2 takes longer than the rest of the step unless it never pauses.  The loads sit BEHIND the
-// exchange on purpose: the granule store and the polls travel through the same per-CU vector-memory queue and
-// would wait for every column load issued before them.  DEPTH 1 (the variant without room for five buffers): two x
-// buffers, one a buffer, requested behind barrier 1 and awaited in full by the next sweep.
-template <int RT, int MODE, int MAXW, int DEPTH>
-__global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p)
+// Cooperative plan (rows split by columns over C workgroups): the column buffers and the RT residual rows of every
+// sweep wave live in the column window (gpfq_device.h), as in the resident kernel below.
+// DEPTH = look-ahead of the column loads in steps.
+//   DEPTH 2: three x buffers and two a buffers rotate by name in a six-fold unrolled loop (x_t in X[t % 3], a_t in
+//     A[t % 2]); column t+2 is requested into the registers sweep t has finished with, three quarters behind the lane
+//     tree and the last one behind barrier 2, and sweep t+1 waits for column t+1 only (vmcnt(8)).  With 12 waves a
+//     workgroup pulls 96 KB of columns per step through the CU's vector-memory pipe, which takes longer than the rest
+//     of the step unless it never pauses -- and the granule store and the polls of the exchange travel through the
+//     same per-CU queue and wait for every request ahead of them.  Measured on the ResNet-50 shapes: all eight
+//     requests behind barrier 2 (the queue is empty for the exchange, but every wave then stalls issuing into a full
+//     queue before its next sweep) 2.45 / 1.84 / 2.33 us per column, this split 2.30 / 1.74 / 2.28, all of them behind
+//     the lane tree 2.61 / 1.75 / 2.27.
+//   DEPTH 1 (four rows at 12 waves: 168 registers hold the four rows and three column buffers, not five): two x
+//     buffers alternate, one a buffer; column t+1 is requested into the registers sweep t has finished with -- it has
+//     the whole exchange to land -- and sweep t+1 waits for all of it (vmcnt(0)).
+// WB = first register of the window: x buffers, a buffers, then the RT residual rows.
+template <int RT, int MODE, int DEPTH, int WB>
+__device__ __forceinline__ void coop_body(const SlabParams& p)
 {
+    constexpr int NX = DEPTH == 2 ? 3 : 2, NA = DEPTH == 2 ? 2 : 1;
+    constexpr int X0 = WB, X1 = WB + 16, X2 = WB + 32, A0 = WB + 16 * NX, A1 = A0 + 16, U0 = WB + 16 * (NX + NA);
     extern __shared__ float smem[];                 // seg[2][RT][NW], then qs[2][RT + 1], then the Q / idx history
     const int NW = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -273,46 +295,46 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
 
     const int row0 = tile * RT;
     const int64_t grow0 = row0;                     // groups == 1
-    const int64_t kbase = (int64_t)myseg * kSeg + 4 * lane;
     const float* xload = uniform_ptr(p.XT + (int64_t)myseg * kSeg);      // wave-uniform column pointers
     const float* aload = uniform_ptr(p.AT + (int64_t)myseg * kSeg);
     const unsigned lane_off = 16u * (unsigned)lane;
     const kfloat* nrm = as_scalar(p.nrm2);
 
-    float u[RT][16];
     const kfloat* wrow[RT];
     float qprev[RT], wcur[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
         wrow[r] = as_scalar(p.W + gr * p.ldw);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;   // a non-zero initial residual is the streaming plan's job
         qprev[r] = 0.0f;
         wcur[r] = wrow[r][0];
     }
     float n2cur = nrm[0];
 
-    Col16 X0, X1, X2, A0, A1;                       // X2, A1 unused (and optimised away) at DEPTH 1
-    zero16(X0); zero16(X1); zero16(X2); zero16(A0); zero16(A1);
+    // the residual starts at 0 (a non-zero initial residual is the streaming plan's job); every buffer starts defined
+    win_zero16<U0>();
+    if constexpr (RT >= 2) win_zero16<U0 + 16>();
+    if constexpr (RT >= 4) { win_zero16<U0 + 32>(); win_zero16<U0 + 48>(); }
+    win_zero16<X0>(); win_zero16<X1>(); win_zero16<A0>();
+    if constexpr (DEPTH == 2) { win_zero16<X2>(); win_zero16<A1>(); }
     if constexpr (DEPTH == 2) {
         // x_0 -> X0, a_0 -> A0, x_1 -> X1, a_1 -> A1 (a one-column layer re-reads column 0); X2 = x_{-1} = 0
         if (active) {
-            load16_async(X0, xload, lane_off);
-            load16_async(A0, aload, lane_off);
+            win_load16<X0>(xload, lane_off);
+            win_load16<A0>(aload, lane_off);
         }
         const int64_t adv = (1 < p.d) ? p.m_pad : 0;
         xload += adv;
         aload += adv;
         if (active) {
-            load16_async(X1, xload, lane_off);
-            load16_async(A1, aload, lane_off);
+            win_load16<X1>(xload, lane_off);
+            win_load16<A1>(aload, lane_off);
         }
     } else {
         // x_0 -> X0, a_0 -> A0; X1 = x_{-1} = 0
         if (active) {
-            load16_sync(X0, xload, lane_off);
-            load16_sync(A0, aload, lane_off);
+            win_load16<X0>(xload, lane_off);
+            win_load16<A0>(aload, lane_off);
         }
     }
 
@@ -335,8 +357,9 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
 #endif
     int t = 0;
     bool dead = false;
-    // one step; xprev = x_{t-1}, xcur = x_t, acur = a_t.  Returns false after the last column or on a timeout.
-    auto step = [&](Col16& xprev, Col16& xcur, Col16& acur) -> bool {
+    // one step; XP holds x_{t-1}, XC x_t, AC a_t.  Returns false after the last column or on a timeout.
+    auto step = [&](auto xp_, auto xc_, auto ac_) -> bool {
+        constexpr int XP = decltype(xp_)::value, XC = decltype(xc_)::value, AC = decltype(ac_)::value;
         GPFQ_STAMP(0)
         const int par = t & 1;
         const bool more = t + 1 < p.d;
@@ -351,49 +374,37 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
         // the pointers advance in every wave (uniform values must not change under a per-wave condition, or they
         // stop being scalar); the last steps re-read the last column rather than branch
         {
-            int64_t adv = (t + DEPTH < p.d) ? p.m_pad : 0;
-            if constexpr (DEPTH == 1) asm volatile("" : "+s"(adv)::"memory");   // keeps LLVM from hoisting its loads above the sweep
+            const int64_t adv = (t + DEPTH < p.d) ? p.m_pad : 0;
             xload += adv;
             aload += adv;
         }
         if (active) {
-            if constexpr (DEPTH == 2) wait_landed<8>(xcur, acur);   // column t; the loads of column t+1 stay in flight
+            win_wait<DEPTH == 2 ? 8 : 0>();         // column t has landed (DEPTH 2: the loads of column t+1 stay in flight)
             float acc[RT];
-#pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xprev, acur, xcur, qprev[r], wcur[r]);
+            acc[0] = win_sweep16<U0, XP, AC, XC>(qprev[0], wcur[0]);
+            if constexpr (RT >= 2) acc[1] = win_sweep16<U0 + 16, XP, AC, XC>(qprev[1], wcur[1]);
+            if constexpr (RT >= 4) {
+                acc[2] = win_sweep16<U0 + 32, XP, AC, XC>(qprev[2], wcur[2]);
+                acc[3] = win_sweep16<U0 + 48, XP, AC, XC>(qprev[3], wcur[3]);
+            }
             GPFQ_STAMP(1)
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 const float sg = wave_tree64_lane63(acc[r]);
                 if (lane == 63) seg[r * NW + wave] = sg;
             }
-            // Column t+2 into the registers sweep t has finished with (x_{t-1}'s and a_t's): three quarters here,
-            // the last one behind barrier 2.  Measured on the ResNet-50 shapes against every other split that the
-            // build's ISA check accepts: all eight requests behind barrier 2 (the queue is empty for the exchange,
-            // but every wave then stalls issuing into a full queue before its next sweep) 2.45 / 1.84 / 2.33 us per
-            // column, this split 2.30 / 1.74 / 2.28; all of them here 2.61 / 1.75 / 2.27 (the granule store and the
-            // polls of the exchange travel through the same per-CU queue and wait for every request ahead of them).
-            // Requests right behind the sweep make LLVM copy registers that are in flight (RT >= 2): rejected by
-            // tools/check_async_loads.py.
-            if constexpr (DEPTH == 2) {
-                load4_async<0>(xprev, xload, lane_off);
-                load4_async<0>(acur, aload, lane_off);
-                load4_async<1>(xprev, xload, lane_off);
-                load4_async<1>(acur, aload, lane_off);
-                load4_async<2>(xprev, xload, lane_off);
-                load4_async<2>(acur, aload, lane_off);
-            }
+            // the next column wanted into the registers the sweeps have just finished with (x_{t-1}'s and a_t's): three
+            // quarters here, the last one behind barrier 2
+            win_load4<XP, 0>(xload, lane_off);
+            win_load4<AC, 0>(aload, lane_off);
+            win_load4<XP, 1>(xload, lane_off);
+            win_load4<AC, 1>(aload, lane_off);
+            win_load4<XP, 2>(xload, lane_off);
+            win_load4<AC, 2>(aload, lane_off);
             GPFQ_STAMP(2)
         }
         __syncthreads();
         GPFQ_STAMP(3)
-        if constexpr (DEPTH == 1) {
-            // one step of look-ahead only, compiler-managed: the loads cannot wait for the exchange
-            if (active) {
-                load16_sync(xprev, xload, lane_off);
-                load16_sync(acur, aload, lane_off);
-            }
-        }
         if (wave == rwave) {
             GPFQ_STAMP(4)
             reducer_section<RT, MODE>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, row0, grow0, seg_lo);
@@ -402,11 +413,9 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
         GPFQ_STAMP(6)
         __syncthreads();
         GPFQ_STAMP(7)
-        if constexpr (DEPTH == 2) {
-            if (active) {
-                load4_async<3>(xprev, xload, lane_off);
-                load4_async<3>(acur, aload, lane_off);
-            }
+        if (active) {
+            win_load4<XP, 3>(xload, lane_off);
+            win_load4<AC, 3>(aload, lane_off);
         }
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
@@ -418,28 +427,26 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
         ++t;
         return true;
     };
+    using I0 = std::integral_constant<int, X0>; using I1 = std::integral_constant<int, X1>; using I2 = std::integral_constant<int, X2>;
+    using J0 = std::integral_constant<int, A0>; using J1 = std::integral_constant<int, A1>;
     int k = 0;                                       // buffer that holds x_t when the loop ends
     if constexpr (DEPTH == 2) {
         for (;;) {
-            k = 0; if (!step(X2, X0, A0)) break;
-            k = 1; if (!step(X0, X1, A1)) break;
-            k = 2; if (!step(X1, X2, A0)) break;
-            k = 0; if (!step(X2, X0, A1)) break;
-            k = 1; if (!step(X0, X1, A0)) break;
-            k = 2; if (!step(X1, X2, A1)) break;
+            k = 0; if (!step(I2{}, I0{}, J0{})) break;
+            k = 1; if (!step(I0{}, I1{}, J1{})) break;
+            k = 2; if (!step(I1{}, I2{}, J0{})) break;
+            k = 0; if (!step(I2{}, I0{}, J1{})) break;
+            k = 1; if (!step(I0{}, I1{}, J0{})) break;
+            k = 2; if (!step(I1{}, I2{}, J1{})) break;
         }
     } else {
         for (;;) {
-            k = 0; if (!step(X1, X0, A0)) break;
-            k = 1; if (!step(X0, X1, A0)) break;
+            k = 0; if (!step(I1{}, I0{}, J0{})) break;
+            k = 1; if (!step(I0{}, I1{}, J0{})) break;
         }
     }
-    // every load issued above has landed before the buffers are looked at again
-    if constexpr (DEPTH == 2) {
-        wait_landed<0>(X0, X1);
-        wait_landed<0>(X2, A0);
-        wait_landed<0>(A1);
-    }
+    // every load issued above has landed before the last column is used again (and before the wave ends)
+    win_wait<0>();
 #ifdef GPFQ_STAMPS
     if (blockIdx.x == 0 && lane == 0 && (wave == rwave || wave == (rwave == 0 ? NW - 1 : 0)) && p.status) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.status + 16) + (wave == rwave ? 0 : 8);
@@ -447,10 +454,38 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
     }
 #endif
     if (dead || !active) return;
-    if (k == 0) finish_rows<RT>(p, u, qprev, X0, row0, grow0, kbase, myseg, lane);
-    else if (k == 1) finish_rows<RT>(p, u, qprev, X1, row0, grow0, kbase, myseg, lane);
-    else finish_rows<RT>(p, u, qprev, X2, row0, grow0, kbase, myseg, lane);
+    auto finish = [&](auto xl_) {
+        constexpr int XL = decltype(xl_)::value;
+        finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, myseg, lane);
+        if constexpr (RT >= 2) finish_row_w<U0 + 16, XL>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, myseg, lane);
+        if constexpr (RT >= 4) {
+            finish_row_w<U0 + 32, XL>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, myseg, lane);
+            finish_row_w<U0 + 48, XL>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, myseg, lane);
+        }
+    };
+    if (k == 0) finish(I0{});
+    else if (k == 1) finish(I1{});
+    else if constexpr (DEPTH == 2) finish(I2{});
 }
+
+// One __global__ per (rows per workgroup, quantizer, wave bound): see GPFQ_DEFINE_RESIDENT below for the attribute.
+#define GPFQ_DEFINE_COOP(RT, MODE, MAXW, DEPTH, WB, LAST)                                                         \
+    __global__ void __launch_bounds__(64 * MAXW) __attribute__((amdgpu_num_vgpr(WB / 2)))                          \
+    gpfq_coop_rt##RT##_m##MODE##_w##MAXW(const SlabParams p)                                                     \
+    {                                                                                                             \
+        asm volatile("" ::: LAST);      /* makes the kernel descriptor allocate the whole budget */               \
+        coop_body<RT, MODE, DEPTH, WB>(p);                                                                        \
+    }
+#define GPFQ_DEFINE_COOP_MODES(RT, MAXW, DEPTH, WB, LAST)                                                         \
+    GPFQ_DEFINE_COOP(RT, 0, MAXW, DEPTH, WB, LAST) GPFQ_DEFINE_COOP(RT, 1, MAXW, DEPTH, WB, LAST)                 \
+    GPFQ_DEFINE_COOP(RT, 2, MAXW, DEPTH, WB, LAST) GPFQ_DEFINE_COOP(RT, 3, MAXW, DEPTH, WB, LAST)
+GPFQ_DEFINE_COOP_MODES(1, 12, 2, 72, "v167")       // 168 - 80 - 16
+GPFQ_DEFINE_COOP_MODES(2, 8, 2, 144, "v255")       // 256 - 80 - 32
+GPFQ_DEFINE_COOP_MODES(2, 12, 2, 56, "v167")       // 168 - 80 - 32
+GPFQ_DEFINE_COOP_MODES(4, 8, 2, 112, "v255")       // 256 - 80 - 64
+// 168 - 48 - 64: three column buffers, one step of look-ahead.  No stochastic variant: the Philox rounds do not fit
+// the 56 registers left (two would spill); the host streams that combination instead (launch_coop -> UNSUPPORTED).
+GPFQ_DEFINE_COOP(4, 0, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 1, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 2, 12, 1, 56, "v167")
 
 // ------------------------------------------------------------------------------------------------
 // Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE
@@ -471,40 +506,6 @@ __global__ void __launch_bounds__(64 * MAXW) gpfq_coop_kernel(const SlabParams p
 // cycles, so it is also kept free of taken branches (each ~20 cycles): no level tests in the slot tree, no "is there
 // a next column" test, the rare Q / idx flush out of line.
 // ------------------------------------------------------------------------------------------------
-// Tail of the window kernels for one row: the pending subtraction of the last step (in place, in the window), then the
-// residual leaves the registers four elements at a time (step_algorithm.py:148), with the fused sum of squares.
-template <int U, int XL>
-__device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, bool valid, int64_t grow, int64_t kbase, int seg, int lane)
-{
-    win_final_sub16<U, XL>(qlast);
-    if (!valid) return;
-    float* Urow = p.U + grow * p.ldu;
-    float acc = 0.0f;
-    auto chunk = [&](auto c_) {
-        constexpr int c = decltype(c_)::value;
-        float v[4];
-        win_read4<U + 4 * c>(v);
-        const int64_t k0 = kbase + 256 * c;
-        if (p.vec && k0 + 3 < p.m) {
-            *reinterpret_cast<float4*>(Urow + k0) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k0 + j < p.m) Urow[k0 + j] = v[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(v[j], v[j], acc);       // element order e = 4c + j, as store_segment_sumsq
-    };
-    chunk(std::integral_constant<int, 0>{});
-    chunk(std::integral_constant<int, 1>{});
-    chunk(std::integral_constant<int, 2>{});
-    chunk(std::integral_constant<int, 3>{});
-    if (p.usq) {
-        const float sg = wave_tree64_lane63(acc);
-        if (lane == 63) p.usq[grow * p.S + seg] = sg;
-    }
-}
-
 // WB = first register of the window = the kernel's register budget minus 80 + 16 RT (see GPFQ_DEFINE_RESIDENT below):
 // three x buffers, two a buffers, then the RT residual rows.
 template <int RT, int MODE, int WB>
@@ -522,7 +523,6 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
     const bool occupied = (smap.mask & 1u) && (lane & 15) < P && r16 < RT;   // other lanes contribute +0.0f
     const int seg_off = (r16 < RT ? r16 : 0) * S + smap.s0;                  // a valid LDS word in every lane
     const int64_t grow0 = (int64_t)g * p.Ng + row0;
-    const int64_t kbase = (int64_t)wave * kSeg + 4 * lane;
     const float* xload = uniform_ptr(p.XT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const float* aload = uniform_ptr(p.AT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const unsigned lane_off = 16u * (unsigned)lane;
@@ -701,11 +701,11 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
     win_wait<0>();
     auto finish = [&](auto xl_) {
         constexpr int XL = decltype(xl_)::value;
-        finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, kbase, wave, lane);
-        if constexpr (RT >= 2) finish_row_w<U0 + 16, XL>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, kbase, wave, lane);
+        finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, wave, lane);
+        if constexpr (RT >= 2) finish_row_w<U0 + 16, XL>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, wave, lane);
         if constexpr (RT >= 4) {
-            finish_row_w<U0 + 32, XL>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, kbase, wave, lane);
-            finish_row_w<U0 + 48, XL>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, kbase, wave, lane);
+            finish_row_w<U0 + 32, XL>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, wave, lane);
+            finish_row_w<U0 + 48, XL>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, wave, lane);
         }
     };
     if (k == 0) finish(I0{});
