@@ -111,3 +111,33 @@ def test_the_built_isa_passes():
         checked += has
         bad += problems
     assert checked >= 20 and bad == []
+
+
+# ---- column-window kernels (registers written as base+offset sums, reserved from the compiler) ----------------------
+def win_load(base, q):
+    return ["\t;;#ASMSTART", "\tglobal_load_dwordx4 v[%d+%d:%d+%d+3], v8, s[38:39] offset:%d" % (base, 4 * q, base, 4 * q, 1024 * q),
+            "\t;;#ASMEND"]
+
+
+def test_register_expressions_are_parsed():
+    assert cal.regs_of("v[176+4:176+4+3]") == {180, 181, 182, 183}
+    assert cal.regs_of("v[192+14]") == {206}
+    assert cal.vregs("\tv_pk_mul_f32 v[20:21], v[18:19], v[192+0:192+1] op_sel_hi:[0,1]") == {18, 19, 20, 21, 192, 193}
+
+
+def test_window_kernel_passes_when_the_compiler_stays_below_the_window():
+    body = win_load(176, 0) + win_load(192, 0) + ["\tv_add_f32_e32 v20, v21, v22"] + asm_wait(0) + \
+        ["\t;;#ASMSTART", "\tv_fmac_f32 v15, v[240+0], v[176+0]", "\t;;#ASMEND", "\tv_add_f32_dpp v15, v15, v15 quad_perm:[1,0,3,2]"]
+    assert run(body) == []
+
+
+def test_compiler_code_in_the_window_is_caught():
+    bad = run(win_load(176, 0) + asm_wait(0) + ["\tv_mov_b32_e32 v177, v3"])
+    assert len(bad) == 1 and "column-window" in bad[0] and "[177]" in bad[0]
+    bad = run(win_load(176, 0) + asm_wait(0) + ["\tglobal_store_dwordx4 v[4:5], v[252:255], off"])
+    assert len(bad) == 1 and "window starts at v176" in bad[0]
+
+
+def test_spill_in_a_window_kernel_is_caught():
+    bad = run(win_load(176, 0) + asm_wait(0) + ["\tscratch_store_dword off, v3, off offset:4"])
+    assert len(bad) == 1 and "spills" in bad[0]
