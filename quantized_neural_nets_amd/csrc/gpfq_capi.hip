@@ -48,7 +48,6 @@ struct Plan {
     int S;         // segments per row
     int C;         // coop: members per row tile
     int tiles;     // coop: row tiles
-    int dual;      // coop: 1 = pipelined kernel, two row tiles per workgroup (grid = ceil(tiles / 2) * C)
 };
 
 int device_cu_count()
@@ -123,29 +122,6 @@ double resident_step_cost(int64_t Ng, int S, int cus)
 bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullptr)
 {
     const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
-    pl->dual = 0;
-    // Pipelined variant (two row tiles per workgroup, the exchange of one hidden behind the sweeps of the other): taken
-    // whenever a configuration exists with at most six sweep waves per member (eight waves = one workgroup per CU at
-    // the kernel's 256 registers) -- most rows per tile first, then the fewest members that still fit.
-    const int dual_mode = env_int("GPFQ_COOP_DUAL", 0);
-    if (dual_mode) {
-        for (int RT = 4; RT >= 1; RT >>= 1) {
-            if (force_rt && RT != force_rt) continue;
-            const int64_t tiles = (Ng + RT - 1) / RT;
-            if (tiles < 2) continue;
-            const int64_t groups = (tiles + 1) / 2;
-            for (int C = 2; C <= 64 / RT && C <= S; C <<= 1) {
-                if (force_c && C != force_c) continue;
-                if (groups * C > cus) break;
-                const int NWs = (S + C - 1) / C;
-                if (NWs > 6) continue;
-                if (!force_c && groups * C * 2 <= cus && C * 2 <= 64 / RT && C * 2 <= S) continue;   // room for twice the members: spread out
-                pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NWs; pl->S = S; pl->dual = 1;
-                if (cost_out) *cost_out = 0.6 + 0.25 * RT + 0.9;      // sweep phase of one tile + one exchange, for two tiles
-                return true;
-            }
-        }
-    }
     const int wgs_per_cu = env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1;
     const int capacity = cus * wgs_per_cu;
     double best = 1e30;
@@ -224,7 +200,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
 int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, Plan* out)
 {
     Plan pl;
-    pl.C = 1; pl.tiles = 0; pl.dual = 0;
+    pl.C = 1; pl.tiles = 0;
     if (m_pad / gpfq::kSeg > 1024) return fail(GPFQ_ERR_UNSUPPORTED, "m > 1048576 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
     if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_STREAM_ROWS) return fail(GPFQ_ERR_ARG, "unknown plan id");
@@ -324,22 +300,6 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
 typedef void (*SlabKernel)(const gpfq::SlabParams);
 
 // the instantiated cooperative (rows per workgroup, wave bound) pairs -- keep slab_max_waves() in step
-SlabKernel coop2_kernel(int RT, int mode)
-{
-#define GPFQ_PICK(RTV)                                                                                                \
-    if (RT == RTV) {                                                                                                  \
-        switch (mode) {                                                                                               \
-        case gpfq::MODE_SOFT: return gpfq::gpfq_coop2_rt##RTV##_m1;                                                   \
-        case gpfq::MODE_HARD: return gpfq::gpfq_coop2_rt##RTV##_m2;                                                   \
-        case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_coop2_rt##RTV##_m3;                                             \
-        default: return gpfq::gpfq_coop2_rt##RTV##_m0;                                                                \
-        }                                                                                                             \
-    }
-    GPFQ_PICK(1) GPFQ_PICK(2) GPFQ_PICK(4)
-#undef GPFQ_PICK
-    return nullptr;
-}
-
 SlabKernel coop_kernel(int RT, int mode, int maxw)
 {
 #define GPFQ_PICK(RTV, MAXWV)                                                                                         \
@@ -364,37 +324,8 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
     return nullptr;
 }
 
-// pipelined cooperative kernel: pl.waves sweep waves + two reducer waves per workgroup, one workgroup per CU
-int launch_coop2(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
-{
-    const int RT = pl.RT;
-    SlabKernel kern = coop2_kernel(RT, mode);
-    if (!kern || pl.waves > 6) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no pipelined cooperative kernel for this configuration");
-    const int nwaves = pl.waves + 2;
-    const int threads = 64 * nwaves;
-    const size_t tile_words = 2 * (size_t)RT * pl.waves + 2 * (RT + 1) + 2 * (size_t)RT * 64;
-    const size_t shm = sizeof(float) * 2 * tile_words + 8 * sizeof(unsigned);
-    const int groups = (pl.tiles + 1) / 2;
-    const int nblocks = groups * pl.C;
-    int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, shm);
-    if (e != hipSuccess) return hip_fail(e, "occupancy query");
-    const int cus = device_cu_count();
-    if (nb < 1 || nblocks > cus) return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
-    size_t xbytes = (size_t)(2 * groups) * 2 * pl.C * RT * sizeof(unsigned long long);
-    xbytes = (xbytes + 15) & ~(size_t)15;
-    if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
-    e = hipMemsetAsync(scratch, 0, xbytes, st);
-    if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, sp);
-    e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "GPFQ pipelined cooperative kernel launch");
-    return GPFQ_OK;
-}
-
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
-    if (pl.dual) return launch_coop2(pl, sp, mode, scratch, st);
     const int RT = pl.RT;
     const int maxw = (RT == 1 || pl.waves > 8) ? 12 : 8;
     SlabKernel kern = coop_kernel(RT, mode, maxw);
@@ -765,10 +696,7 @@ int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, 
     int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, &pl);
     if (rc) return rc;
     if (buf && buf_bytes) {
-        if (pl.kind == GPFQ_PLAN_COOP && pl.dual)
-            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d d=%lld pipelined", pl.RT, pl.C, pl.waves, pl.S,
-                     ((pl.tiles + 1) / 2) * pl.C, (long long)d_g);
-        else if (pl.kind == GPFQ_PLAN_COOP)
+        if (pl.kind == GPFQ_PLAN_COOP)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
                      pl.tiles * pl.C, (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_STREAM && pl.C > 1)

@@ -494,282 +494,6 @@ GPFQ_DEFINE_COOP_MODES(4, 8, 2, 112, "v255")       // 256 - 80 - 64
 GPFQ_DEFINE_COOP(4, 0, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 1, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 2, 12, 1, 56, "v167")
 
 // ------------------------------------------------------------------------------------------------
-// Pipelined cooperative plan: TWO row tiles (A, B) per workgroup, so that a tile's exchange -- one hop between CUs
-// through L2, ~0.8-1.1 us, as long as the sweep phase itself -- runs while the sweep waves work on the other tile.
-//
-//   sweep waves (one per segment of this member):  wait q_A(t-1) | sweep A(t), publish partials | wait q_B(t-1) |
-//                                                  sweep B(t), publish partials | request column t+2 | ...
-//   reducer wave A / B (one each):                 wait for the partials of its tile | slot tree, granule exchange with
-//                                                  the other members, divide, quantize | hand q back | ...
-//
-// A hardware barrier would make the sweep waves wait for the reducers (which are polling other CUs), so the waves of
-// a workgroup meet through LDS words instead: an arrive counter per tile (every sweep wave adds 1 behind its partial
-// sums; the reducer polls it) and a step counter per tile (the reducer stores t+1 behind the q's; the sweep waves
-// poll it).  LDS operations of one wave execute in order, and the partial sums / q's are double-buffered by the
-// parity of t (a wave can be at most one step ahead of the slowest reader: it needs the reader's result to go on).
-// Both tiles share the column registers, so a workgroup pulls every column once for 2 RT rows.
-// Per column two tiles cost max(2 sweep phases, sweep phase + exchange) instead of 2 x (sweep phase + exchange).
-// Every spin is bounded; a timeout raises the status word and a `dead` word in LDS that every wave's spin sees.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)reinterpret_cast<uintptr_t>(p); }
-__device__ __forceinline__ unsigned lds_peek(unsigned addr)
-{
-    unsigned v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return __builtin_amdgcn_readfirstlane(v);       // every lane read the same word: a scalar, so that loops on it are uniform
-}
-__device__ __forceinline__ void lds_poke(unsigned addr, unsigned v)
-{
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-
-template <int RT, int MODE, int WB>
-__device__ __forceinline__ void coop2_body(const SlabParams& p)
-{
-    constexpr int X0 = WB, X1 = WB + 16, X2 = WB + 32, A0 = WB + 48, A1 = WB + 64, UA = WB + 80, UB = UA + 16 * RT;
-    extern __shared__ float smem[];
-    const int NW = blockDim.x >> 6;                 // sweep waves + the two reducers
-    const int NWS = NW - 2;
-    // the wave number as a SCALAR: the roles below are then uniform branches, and the column pointers advanced inside
-    // them stay in SGPRs (a value changed under a condition the compiler cannot prove uniform becomes a vector value)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int S = p.S, C = p.C;
-    const int P = pow2_ceil(S);
-    const int groups = (p.tiles + 1) >> 1;          // pairs of row tiles
-    int grp, c;
-    if ((groups & 7) == 0) {                        // members of one pair on one XCD (speed only)
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        grp = (j / C) * 8 + xcd;
-        c = j % C;
-    } else {
-        grp = blockIdx.x / C;
-        c = blockIdx.x % C;
-    }
-    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
-    const int n_own = seg_hi - seg_lo;              // <= NWS
-    const int nl = P / C;
-    // LDS: per tile seg[2][RT][NWS] and qs[2][RT + 1] + history [2 RT][64]; then the control words
-    const int tile_words = 2 * RT * NWS + 2 * (RT + 1) + 2 * RT * 64;
-    unsigned* ctrl = reinterpret_cast<unsigned*>(smem + 2 * tile_words);      // [0,1] arrive counters, [2,3] steps done, [4] dead
-#ifdef GPFQ_DEBUG_COOP2
-    for (int i = threadIdx.x; i < 2 * tile_words; i += blockDim.x) smem[i] = __uint_as_float(0x7fc00000u);   // poison: a premature read shows
-#endif
-    if (threadIdx.x < 8) ctrl[threadIdx.x] = 0u;
-    __syncthreads();                                // the only barrier: the control words are zero before anyone polls
-    const unsigned a_cnt = lds_addr(ctrl), a_done = lds_addr(ctrl + 2), a_dead = lds_addr(ctrl + 4);
-    const kfloat* nrm = as_scalar(p.nrm2);
-
-    if (wave >= NWS) {
-        // ---------------- reducer of tile X = wave - NWS ----------------
-        const int X = wave - NWS;
-        const int tile = 2 * grp + X;
-        const int row0 = tile * RT;
-        const int64_t grow0 = row0;
-        float* segs = smem + X * tile_words;
-        float* qs = segs + 2 * RT * NWS;
-        const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane & 15, nl);
-        for (int t = 0; t < p.d; ++t) {
-            const unsigned want = (unsigned)n_own * (unsigned)(t + 1);
-            unsigned spins = 0;
-            bool dead = false;
-            // back-to-back polls (an LDS read is ~100 cycles: that is the hand-off latency); the death word only now and then
-            while (lds_peek(a_cnt + 4u * X) < want) {
-                if ((++spins & 63u) == 0u && (lds_peek(a_dead) != 0u || spins > (1u << 24))) { dead = true; break; }
-            }
-#ifdef GPFQ_DEBUG_COOP2
-            if (blockIdx.x == 0 && lane == 0) { p.status[12 + X] = dead ? -(t + 1) : (t + 1); p.status[14 + X] = (int)lds_peek(a_cnt + 4u * X); }
-#endif
-            if (dead) break;
-            const int par = t & 1;
-#ifdef GPFQ_DEBUG_COOP2
-            {
-                const float* sp_ = segs + par * RT * NWS;
-                int bad = 0;
-                for (int r = 0; r < RT; ++r)
-                    for (int w = 0; w < n_own; ++w)
-                        if (sp_[r * NWS + w] != sp_[r * NWS + w]) ++bad;
-                if (bad && lane == 0) { atomicAdd(&p.status[5], bad); p.status[6] = t; p.status[7] = blockIdx.x * 2 + X; }
-            }
-#endif
-            // (the result comes back in a register: a word that lane 0 stores and the other lanes load is a data race
-            // inside one wave -- nothing orders the two -- and the compiler does schedule the loads first)
-            const bool failed = reducer_section<RT, MODE>(p, segs + par * RT * NWS, qs, smap, NWS, nl, lane, tile, c, C, par, t, nrm[t],
-                                                          row0, grow0, seg_lo);
-            // the q's are in LDS: publish the step, or the death
-            if (lane == 0) {
-                if (failed) lds_poke(a_dead, 1u);
-                else lds_poke(a_done + 4u * X, (unsigned)(t + 1));
-#ifdef GPFQ_DEBUG_COOP2
-                if (blockIdx.x == 0) p.status[8 + X] = t + 1;
-#endif
-            }
-            if (failed) break;
-        }
-        return;
-    }
-
-    // ---------------- sweep wave ----------------
-    const bool active = wave < n_own;
-    const int myseg = seg_lo + (active ? wave : 0);
-    const float* xload = uniform_ptr(p.XT + (int64_t)myseg * kSeg);
-    const float* aload = uniform_ptr(p.AT + (int64_t)myseg * kSeg);
-    const unsigned lane_off = 16u * (unsigned)lane;
-    const int rowA = (2 * grp) * RT, rowB = rowA + RT;
-    float* segA = smem;
-    float* segB = smem + tile_words;
-    const float* qsA = segA + 2 * RT * NWS;
-    const float* qsB = segB + 2 * RT * NWS;
-    const kfloat* wA[RT];
-    const kfloat* wB[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        // rows past the end repeat the last row (computed, exchanged, never stored)
-        const int64_t ga = (rowA + r < p.Ng) ? rowA + r : p.Ng - 1;
-        const int64_t gb = (rowB + r < p.Ng) ? rowB + r : p.Ng - 1;
-        wA[r] = as_scalar(p.W + ga * p.ldw);
-        wB[r] = as_scalar(p.W + gb * p.ldw);
-    }
-    if (!active) return;                            // (a member with fewer segments than sweep waves: nothing to sweep)
-
-    win_zero16<UA>(); win_zero16<UB>();
-    if constexpr (RT >= 2) { win_zero16<UA + 16>(); win_zero16<UB + 16>(); }
-    if constexpr (RT >= 4) { win_zero16<UA + 32>(); win_zero16<UA + 48>(); win_zero16<UB + 32>(); win_zero16<UB + 48>(); }
-    win_zero16<X2>();
-    win_load16<X0>(xload, lane_off);
-    win_load16<A0>(aload, lane_off);
-    {
-        const int64_t adv = (1 < p.d) ? p.m_pad : 0;
-        xload += adv;
-        aload += adv;
-    }
-    win_load16<X1>(xload, lane_off);
-    win_load16<A1>(aload, lane_off);
-
-    float qA[RT], qB[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) { qA[r] = 0.0f; qB[r] = 0.0f; }
-    bool dead = false;
-    // wait until the reducer of tile X has finished step t-1, then fetch its q's
-    auto await_q = [&](int X, int t, const float* qs, float (&q)[RT]) {
-        if (t == 0) return;
-        unsigned spins = 0;
-        while (lds_peek(a_done + 4u * X) < (unsigned)t) {
-            if ((++spins & 63u) == 0u && (lds_peek(a_dead) != 0u || spins > (1u << 24))) { dead = true; return; }
-        }
-        const int par = (t - 1) & 1;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) q[r] = qs[par * (RT + 1) + r];
-    };
-    // leave this wave's partial sums of one tile in LDS and arrive (lane 63 holds the sums; its LDS operations execute in order)
-    auto publish = [&](int X, float* seg, const float (&sg)[RT]) {
-        if (lane == 63) {
-#pragma unroll
-            for (int r = 0; r < RT; ++r) lds_poke(lds_addr(seg + r * NWS + wave), __float_as_uint(sg[r]));
-            asm volatile("ds_add_u32 %0, %1" ::"v"(a_cnt + 4u * X), "v"(1u) : "memory");
-        }
-    };
-    int t = 0;
-    auto step = [&](auto xp_, auto xc_, auto ac_) -> bool {
-        constexpr int XP = decltype(xp_)::value, XC = decltype(xc_)::value, AC = decltype(ac_)::value;
-        const int par = t & 1;
-        const bool more = t + 1 < p.d;
-        float wa[RT], wb[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) { wa[r] = wA[r][t]; wb[r] = wB[r][t]; }
-        // ---- tile A
-        await_q(0, t, qsA, qA);
-        if (dead) return false;
-        win_wait<8>();                              // column t has landed; the eight loads of column t+1 stay in flight
-        {
-            float sg[RT];
-            sg[0] = wave_tree64_lane63(win_sweep16<UA, XP, AC, XC>(qA[0], wa[0]));
-            if constexpr (RT >= 2) sg[1] = wave_tree64_lane63(win_sweep16<UA + 16, XP, AC, XC>(qA[1], wa[1]));
-            if constexpr (RT >= 4) {
-                sg[2] = wave_tree64_lane63(win_sweep16<UA + 32, XP, AC, XC>(qA[2], wa[2]));
-                sg[3] = wave_tree64_lane63(win_sweep16<UA + 48, XP, AC, XC>(qA[3], wa[3]));
-            }
-            publish(0, segA + par * RT * NWS, sg);
-        }
-        // ---- tile B (A's exchange is in flight meanwhile)
-        await_q(1, t, qsB, qB);
-        if (dead) return false;
-        {
-            float sg[RT];
-            sg[0] = wave_tree64_lane63(win_sweep16<UB, XP, AC, XC>(qB[0], wb[0]));
-            if constexpr (RT >= 2) sg[1] = wave_tree64_lane63(win_sweep16<UB + 16, XP, AC, XC>(qB[1], wb[1]));
-            if constexpr (RT >= 4) {
-                sg[2] = wave_tree64_lane63(win_sweep16<UB + 32, XP, AC, XC>(qB[2], wb[2]));
-                sg[3] = wave_tree64_lane63(win_sweep16<UB + 48, XP, AC, XC>(qB[3], wb[3]));
-            }
-            publish(1, segB + par * RT * NWS, sg);
-        }
-        // column t+2 into the registers both tiles have finished with (x_{t-1}'s and a_t's); the last two steps re-read
-        // the last column rather than branch
-        {
-            const int64_t adv = (t + 2 < p.d) ? p.m_pad : 0;
-            xload += adv;
-            aload += adv;
-        }
-        win_load16<XP>(xload, lane_off);
-        win_load16<AC>(aload, lane_off);
-#ifdef GPFQ_DEBUG_COOP2
-        if (blockIdx.x == 0 && wave == 0 && lane == 0) p.status[10] = t + 1;
-#endif
-        if (!more) return false;
-        ++t;
-        return true;
-    };
-    using I0 = std::integral_constant<int, X0>; using I1 = std::integral_constant<int, X1>; using I2 = std::integral_constant<int, X2>;
-    using J0 = std::integral_constant<int, A0>; using J1 = std::integral_constant<int, A1>;
-    int k = 0;
-    for (;;) {
-        k = 0; if (!step(I2{}, I0{}, J0{})) break;
-        k = 1; if (!step(I0{}, I1{}, J1{})) break;
-        k = 2; if (!step(I1{}, I2{}, J0{})) break;
-        k = 0; if (!step(I2{}, I0{}, J1{})) break;
-        k = 1; if (!step(I0{}, I1{}, J0{})) break;
-        k = 2; if (!step(I1{}, I2{}, J1{})) break;
-    }
-    win_wait<0>();                                   // every load has landed before the wave goes on (or ends)
-    if (dead) return;
-    // the q's of the last column, then the residual leaves the registers
-    await_q(0, p.d, qsA, qA);
-    await_q(1, p.d, qsB, qB);
-    if (dead) return;
-    auto finish = [&](auto xl_) {
-        constexpr int XL = decltype(xl_)::value;
-        finish_row_w<UA, XL>(p, qA[0], rowA < p.Ng, rowA, myseg, lane);
-        finish_row_w<UB, XL>(p, qB[0], rowB < p.Ng, rowB, myseg, lane);
-        if constexpr (RT >= 2) {
-            finish_row_w<UA + 16, XL>(p, qA[1], rowA + 1 < p.Ng, rowA + 1, myseg, lane);
-            finish_row_w<UB + 16, XL>(p, qB[1], rowB + 1 < p.Ng, rowB + 1, myseg, lane);
-        }
-        if constexpr (RT >= 4) {
-            finish_row_w<UA + 32, XL>(p, qA[2], rowA + 2 < p.Ng, rowA + 2, myseg, lane);
-            finish_row_w<UA + 48, XL>(p, qA[3], rowA + 3 < p.Ng, rowA + 3, myseg, lane);
-            finish_row_w<UB + 32, XL>(p, qB[2], rowB + 2 < p.Ng, rowB + 2, myseg, lane);
-            finish_row_w<UB + 48, XL>(p, qB[3], rowB + 3 < p.Ng, rowB + 3, myseg, lane);
-        }
-    };
-    if (k == 0) finish(I0{});
-    else if (k == 1) finish(I1{});
-    else finish(I2{});
-}
-
-#define GPFQ_DEFINE_COOP2(RT, MODE, WB)                                                                            \
-    __global__ void __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(WB / 2)))                                \
-    gpfq_coop2_rt##RT##_m##MODE(const SlabParams p)                                                              \
-    {                                                                                                             \
-        asm volatile("" ::: "v255");                                                                              \
-        coop2_body<RT, MODE, WB>(p);                                                                              \
-    }
-#define GPFQ_DEFINE_COOP2_MODES(RT, WB) \
-    GPFQ_DEFINE_COOP2(RT, 0, WB) GPFQ_DEFINE_COOP2(RT, 1, WB) GPFQ_DEFINE_COOP2(RT, 2, WB) GPFQ_DEFINE_COOP2(RT, 3, WB)
-GPFQ_DEFINE_COOP2_MODES(1, 144)                    // 256 - 80 - 2 x 16
-GPFQ_DEFINE_COOP2_MODES(2, 112)                    // 256 - 80 - 2 x 32
-GPFQ_DEFINE_COOP2_MODES(4, 48)                     // 256 - 80 - 2 x 64
-
-// ------------------------------------------------------------------------------------------------
 // Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE
 // barrier per step.  Every wave leaves its segment sums in LDS, and behind the barrier every wave finishes the slot
 // tree, divides and quantizes for itself (the same bits in every wave), so q never travels through LDS and there
