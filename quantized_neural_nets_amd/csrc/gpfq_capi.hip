@@ -164,6 +164,8 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
     pl->S = S;
     pl->C = 1;
     pl->RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
+    while (pl->RT > 1 && (size_t)2 * pl->RT * S * sizeof(float) > 48 * 1024) pl->RT >>= 1;   // the segment sums of RT rows live in LDS
+    if (S > 1024 && pl->RT > 2) pl->RT = 2;               // (the four-row kernel has no 32 / 64-slots-per-lane tree)
     pl->tiles = (int)((Ng + pl->RT - 1) / pl->RT);
     pl->waves = S < 8 ? S : 8;
     if (!allow_coop || groups != 1 || env_int("GPFQ_COOP_DISABLE", 0)) return;
@@ -185,6 +187,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
         for (int C = 64 / RT; C >= 2; C >>= 1) {
             if (force_c && C != force_c) continue;
             if (tiles * C > cus || S / C < 8) continue;           // every member keeps >= 8 segments (one per wave)
+            if (RT > 2 && S > 1024 * C) continue;                 // (the four-row kernel has no 32 / 64-slots-per-lane tree)
             const int score = (int)tiles * C * 8 + RT;
             if (score > best_score || (force_c && force_rt)) { best_score = score; best_rt = RT; best_c = C; }
             break;                                                 // largest C for this RT
@@ -201,7 +204,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
 {
     Plan pl;
     pl.C = 1; pl.tiles = 0;
-    if (m_pad / gpfq::kSeg > 1024) return fail(GPFQ_ERR_UNSUPPORTED, "m > 1048576 calibration rows is not supported");
+    if (m_pad / gpfq::kSeg > 4096) return fail(GPFQ_ERR_UNSUPPORTED, "m > 4194304 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
     if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_STREAM_ROWS) return fail(GPFQ_ERR_ARG, "unknown plan id");
     if (requested == GPFQ_PLAN_STREAM_ROWS) {            // whole rows per workgroup: never waits for another workgroup

@@ -109,6 +109,7 @@ __device__ __forceinline__ float wave_tree16_zero_padded(float v)
 struct SlotMap {
     int s0;
     unsigned mask;
+    unsigned mask_hi;      // slots 32..63 of a lane's block (only blocks of 64 slots per lane use it: rows of 2049..4096 segments)
 };
 
 __device__ __forceinline__ SlotMap make_slot_map(int S, int P, int slot_base, int per, int lane, int nl)
@@ -116,13 +117,18 @@ __device__ __forceinline__ SlotMap make_slot_map(int S, int P, int slot_base, in
     SlotMap mp;
     mp.s0 = (slot_base * S + P - 1) / P;      // idle lanes point at the block's first segment (a valid index)
     mp.mask = 0u;
+    mp.mask_hi = 0u;
     if (lane < nl) {
         const int first = slot_base + lane * per;
         int lo = (first * S + P - 1) / P;
         int hi = ((first + per) * S + P - 1) / P;
         if (hi > S) hi = S;
         mp.s0 = lo;
-        for (int sg = lo; sg < hi; ++sg) mp.mask |= 1u << ((sg * P) / S - first);
+        for (int sg = lo; sg < hi; ++sg) {
+            const int bit = (int)(((int64_t)sg * P) / S) - first;
+            if (bit < 32) mp.mask |= 1u << bit;
+            else mp.mask_hi |= 1u << (bit - 32);
+        }
     }
     return mp;
 }
@@ -147,8 +153,33 @@ __device__ __forceinline__ float block_tree(const float* seg, const SlotMap mp, 
     return v[0];
 }
 
+// The same balanced tree over PER = 32 or 64 consecutive slots as a tree of 16-slot blocks, one block at a time (no more
+// registers than block_tree<16>): a balanced pairwise tree over an aligned block IS the tree of its aligned halves.
+// Rows of more than 1024 segments (m > 1 048 576) only.
+template <int PER>
+__device__ __forceinline__ float block_tree_seq(const float* seg, const SlotMap mp, int s_last)
+{
+    static_assert(PER == 32 || PER == 64, "two or four blocks of 16 slots");
+    float part[PER / 16];
+    int s0 = mp.s0;
+#pragma unroll
+    for (int b = 0; b < PER / 16; ++b) {
+        SlotMap sub;
+        sub.mask = ((b < 2 ? mp.mask : mp.mask_hi) >> (16 * (b & 1))) & 0xffffu;
+        sub.mask_hi = 0u;
+        sub.s0 = s0;
+        part[b] = block_tree<16>(seg, sub, s_last);
+        s0 += __builtin_popcount(sub.mask);           // segments sit in slot order
+    }
+    if (PER == 32) return part[0] + part[1];
+    return (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // tree over the slot block [slot_base, slot_base + per*nl) of one row; seg = the row's segment sums
 // (indexed by segment number relative to seg_base); result wave-uniform.
+// BIG: also handle 32 / 64 slots per lane (rows of 1025..4096 segments); the four-row streaming kernel is compiled
+// without (its register budget is full, and the host never gives it such rows).
+template <bool BIG>
 __device__ __forceinline__ float combine_slots(const float* seg, const SlotMap mp, int per, int nl, int s_last)
 {
     float v;
@@ -157,6 +188,8 @@ __device__ __forceinline__ float combine_slots(const float* seg, const SlotMap m
     case 4: v = block_tree<4>(seg, mp, s_last); break;
     case 8: v = block_tree<8>(seg, mp, s_last); break;
     case 16: v = block_tree<16>(seg, mp, s_last); break;
+    case 32: if constexpr (BIG) v = block_tree_seq<32>(seg, mp, s_last); else v = 0.0f; break;
+    case 64: if constexpr (BIG) v = block_tree_seq<64>(seg, mp, s_last); else v = 0.0f; break;
     default: v = block_tree<1>(seg, mp, s_last); break;
     }
     v = wave_tree_n(v, nl);

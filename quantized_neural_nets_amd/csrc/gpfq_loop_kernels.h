@@ -984,7 +984,7 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCo
             float mine = 0.0f;
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                const float pr = combine_slots(seg + r * n_max - seg_lo, smap, per, nl, seg_hi - 1);
+                const float pr = combine_slots<(RT <= 2)>(seg + r * n_max - seg_lo, smap, per, nl, seg_hi - 1);
                 if (lane == r) mine = pr;
             }
             float v = mine;

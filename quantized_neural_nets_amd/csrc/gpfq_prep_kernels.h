@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) gpfq_colnorm_kernel(const float* __restri
         const int P = pow2_ceil(S);
         const int per = P > 64 ? P / 64 : 1, nl = P > 64 ? 64 : P;
         const SlotMap smap = make_slot_map(S, P, 0, per, lane, nl);
-        float tot = combine_slots(seg, smap, per, nl, S - 1);
+        float tot = combine_slots<true>(seg, smap, per, nl, S - 1);
         float r = sqrtf(tot);
         if (lane == 0) nrm2[blockIdx.x] = r * r;
     }

@@ -6,9 +6,13 @@
 Models come from torchvision when it is installed (pretrained=True needs its checkpoint cache); without
 torchvision only `alexnet` is available, as a randomly initialised copy of the architecture, which together with
 --synthetic (random calibration batches instead of the ImageNet loader) is enough to run the whole plumbing.
-Dataset evaluation and the CSV log of the reference (main.py:138-177) are only done when a test loader exists.
+Like the reference, every run appends one row to a CSV log (main.py:166-177; same 20 columns, written with the
+header when the file is new) and, with --save_dir, saves the quantized nn.Module under the reference's file name
+(main.py:127-136).  Accuracy columns are evaluated when a test loader exists (main.py:138-159); with --synthetic
+there is none and they stay empty.
 """
 import argparse
+import csv
 import os
 from datetime import datetime
 
@@ -40,7 +44,10 @@ def build_parser():
     # additions of this build
     p.add_argument('--synthetic', action='store_true', help='random calibration batches instead of the dataset loader')
     p.add_argument('--image_size', default=224, type=int, help='side of the synthetic images')
-    p.add_argument('--save_dir', default=None, help='where to torch.save the quantized model (default: not saved)')
+    p.add_argument('--save_dir', default=None, help='where to torch.save the quantized model, as main.py:127-136 does under '
+                                                   '../quantized_models/ (default: not saved)')
+    p.add_argument('--log_file', default=os.path.join('logs', 'Quantization_Log.csv'),
+                   help="CSV log every run appends a row to (the reference's ../logs/Quantization_Log.csv); '' disables")
     p.add_argument('--save_packed', default=None, help='write the quantized model as packed alphabet indices + steps to this file')
     return p
 
@@ -83,6 +90,41 @@ class SyntheticLoader:
             yield torch.randn(self.bs, 3, self.hw, self.hw, generator=self.gen), torch.zeros(self.bs, dtype=torch.long)
 
 
+# the columns of the reference's log (main.py:13-14 `fields`, logs/Quantization_Log.csv), in its order
+LOG_FIELDS = ['Model Name', 'Dataset', 'Quantization Batch Size', 'Original Top1 Accuracy', 'Quantized Top1 Accuracy',
+              'Original Top5 Accuracy', 'Quantized Top5 Accuracy', 'Bits', 'MLP_Alphabet_Scalar', 'CNN_Alphabet_Scalar',
+              'MLP_Percentile', 'CNN_Percentile', 'Stochastic Quantization', 'Regularizer', 'Lambda', 'Original Sparsity',
+              'Quantized Sparsity', 'Retain_rate', 'Fusion', 'Seed']
+
+# FP32 top-1 / top-5 of the un-quantized torchvision models, as the reference tabulates them (main.py:65-74)
+ORIGINAL_ACCURACY = {
+    'alexnet': (.56522, .79066), 'vgg16': (.71592, .90382), 'resnet18': (.69758, .89078), 'googlenet': (.69778, .89530),
+    'resnet50': (.7613, .92862), 'efficientnet_b1': (.7761, .93596), 'efficientnet_b7': (.84122, .96908),
+    'mobilenet_v2': (.71878, .90286)}
+
+
+def saved_model_name(args, bits, bs, mlp_s, cnn_s, mlp_per, cnn_per, lamb):
+    """File name of the saved quantized model, main.py:127-129 (the reference's f-string carries the indentation of
+    its continuation lines into the name; that whitespace is not reproduced)."""
+    return (f'ds{args.data_set}_b{bits}_batch{bs}_mlpscalar{mlp_s}_cnnscalar{cnn_s}_mlppercentile{mlp_per}'
+            f'_cnnpercentile{cnn_per}_retain_rate{args.retain_rate}_reg{args.regularizer}_lambda{lamb}.pt')
+
+
+def append_log_row(path, row):
+    """One row per run, main.py:166-177; the header goes in when the file is new (the reference writes it once at
+    import time, main.py:13-16 / logs/Quantization_Log.csv)."""
+    assert len(row) == len(LOG_FIELDS)
+    d = os.path.dirname(path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    new = not os.path.exists(path) or os.path.getsize(path) == 0
+    with open(path, 'a', newline='') as f:
+        w = csv.writer(f)
+        if new:
+            w.writerow(LOG_FIELDS)
+        w.writerow(row)
+
+
 def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
     if not torch.cuda.is_available():
         raise SystemExit("this build runs on the MI355X only (no CPU path)")
@@ -118,18 +160,27 @@ def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
     print(f'\nTime used for quantization: {datetime.now() - start}\n')
     if args.save_dir:
         os.makedirs(os.path.join(args.save_dir, args.model), exist_ok=True)
-        name = (f'ds{args.data_set}_b{bits}_batch{bs}_mlpscalar{mlp_s}_cnnscalar{cnn_s}_mlppercentile{mlp_per}'
-                f'_cnnpercentile{cnn_per}_retain_rate{args.retain_rate}_reg{args.regularizer}_lambda{lamb}.pt')
-        torch.save(quantized_model, os.path.join(args.save_dir, args.model, name))
+        torch.save(quantized_model, os.path.join(args.save_dir, args.model,
+                                                 saved_model_name(args, bits, bs, mlp_s, cnn_s, mlp_per, cnn_per, lamb)))
     if args.save_packed:
         from . import packed
         info = packed.save(args.save_packed, quantizer)
         print("Packed checkpoint %s: %d layers, %.2f MB of indices for %.2f MB of fp32 weights"
               % (args.save_packed, info["layers"], info["packed_bytes"] / 1e6, info["fp32_bytes"] / 1e6))
+    orig_acc, acc = ('', ''), ('', '')
     if test_loader is not None:
+        orig_acc = ORIGINAL_ACCURACY.get(args.model) or test_accuracy(model, test_loader, device, (1, 5))
+        print(f'Top-1 accuracy of {args.model} is {orig_acc[0]}.')
+        print(f'Top-5 accuracy of {args.model} is {orig_acc[1]}.')
         acc = test_accuracy(quantized_model, test_loader, device, (1, 5))
-        print(f'Top-1 / top-5 accuracy of quantized {args.model}: {acc[0]} / {acc[1]}')
-    print("Sparsity: Org: {}, Quant: {}".format(eval_sparsity(model), eval_sparsity(quantized_model)))
+        print(f'Top-1 accuracy of quantized {args.model} is {acc[0]}.')
+        print(f'Top-5 accuracy of quantized {args.model} is {acc[1]}.')
+    original_sparsity, quantized_sparsity = eval_sparsity(model), eval_sparsity(quantized_model)
+    print("Sparsity: Org: {}, Quant: {}".format(original_sparsity, quantized_sparsity))
+    if args.log_file:
+        append_log_row(args.log_file, [args.model, args.data_set, bs, orig_acc[0], acc[0], orig_acc[1], acc[1], bits, mlp_s, cnn_s,
+                                       mlp_per, cnn_per, args.stochastic_quantization, args.regularizer, lamb,
+                                       original_sparsity, quantized_sparsity, args.retain_rate, args.fusion, args.seed])
     return quantizer
 
 

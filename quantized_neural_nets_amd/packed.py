@@ -84,7 +84,7 @@ def save(path, quantizer):
 
 def load(path, model, device=None):
     """Rebuild the quantized weights into `model` (same architecture); returns it."""
-    blob = torch.load(path, map_location="cpu", weights_only=False)
+    blob = torch.load(path, map_location="cpu", weights_only=True)
     if blob.get("format") != FORMAT:
         raise ValueError("not a %s file" % FORMAT)
     state = dict(blob["state_dict"])

@@ -118,11 +118,25 @@ def test_driver_matches_reference_without_fused_capture():
         qnn.FUSED_CAPTURE = True
 
 
-def test_cli_alexnet_plumbing_config(capsys):
+def test_cli_alexnet_plumbing_config(capsys, tmp_path):
     """BASELINE.json configs[0] on the GPU: `main.py -model alexnet -b 4 -bs 32 -s 1.16` (random-init AlexNet
-    architecture, synthetic calibration batches): all 8 layers are quantized to the 17-level 4-bit alphabet."""
+    architecture, synthetic calibration batches): all 8 layers are quantized to the 17-level 4-bit alphabet; the run
+    appends its row to the CSV log (main.py:166-177) and saves the model under the reference's name (main.py:127-136)."""
+    import csv
     from quantized_neural_nets_amd import main as cli
-    q = cli.main(["-model", "alexnet", "-b", "4", "-bs", "32", "-s", "1.16", "--synthetic"])
+    log = str(tmp_path / "logs" / "Quantization_Log.csv")
+    q = cli.main(["-model", "alexnet", "-b", "4", "-bs", "32", "-s", "1.16", "--synthetic", "--log_file", log,
+                  "--save_dir", str(tmp_path / "quantized_models")])
+    rows = list(csv.reader(open(log)))
+    assert rows[0] == cli.LOG_FIELDS and len(rows) == 2 and len(rows[1]) == 20
+    assert rows[1][:3] == ["alexnet", "ILSVRC2012", "32"] and rows[1][7:10] == ["4", "1.16", "1.16"]
+    assert rows[1][12:15] == ["False", "", "0.1"] and rows[1][17:] == ["0.25", "False", "0"]
+    assert 0.0 <= float(rows[1][15]) <= float(rows[1][16]) < 1.0            # quantization only adds zeros
+    saved = tmp_path / "quantized_models" / "alexnet" / ("dsILSVRC2012_b4_batch32_mlpscalar1.16_cnnscalar1.16_mlppercentile1"
+                                                         "_cnnpercentile1_retain_rate0.25_regNone_lambda0.1.pt")
+    assert saved.exists()
+    reloaded = torch.load(saved, weights_only=False)
+    assert torch.equal(reloaded[0].weight.cpu(), q.quantized_network_layers[0].weight.cpu())
     layers = q.quantized_network_layers
     assert len(layers) == 8 and len(q.layer_reports) == 8
     for rep in q.layer_reports:

@@ -320,3 +320,24 @@ def test_c_abi_argument_errors(qnn):
     assert rc == -1 and b"bad argument" in _lib.lib.gpfq_last_error()
     with pytest.raises(_lib.GpfqError):
         _lib.describe_plan(64, 9, 100000, 1, _lib.PLAN_RESIDENT)
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 1_100_000, "msq"), (2, 2, 2_200_000, "soft"), (5, 2, 4_194_304, "msq")])
+@pytest.mark.parametrize("plan", [0, 1, 4])
+def test_rows_longer_than_a_million_samples(qnn, oracle_mod, shape, plan):
+    """m > 1 048 576 (EfficientNet-B1's 112x112 1x1 convs see 3.2 M calibration rows at batch 1024): 1025..4096
+    segments per row, i.e. 32 or 64 slots per lane in the second level of the canonical tree -- on the cooperative
+    streaming plan, on whole-row streaming (the fallback plan), bit-exact against the oracle; one more segment is refused."""
+    from quantized_neural_nets_amd import _lib
+    N, d, m, mode = shape
+    reg = {"msq": None, "soft": "L1"}[mode]
+    case = dict(name="long_%d" % m, N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg=reg, lamb=0.02, groups=1,
+                first_layer=False, zero_every=0, seed=5)
+    W, A, X = gi.make_inputs(case)
+    r = _run_layer(qnn, case, W, A, X, plan)
+    o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, reg, 0.02, 1)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+    assert abs(float(r["quantize_error"]) - o["quantize_error"]) <= 1e-4 * o["quantize_error"]
+    with pytest.raises(_lib.GpfqError):
+        _lib.describe_plan(4, 4, 4_194_305)

@@ -77,7 +77,7 @@ def test_plan_selection(lib):
         desc = lib.describe_plan(*shape, 1, lib.PLAN_STREAM_ROWS)
         assert desc.startswith("stream") and " C=" not in desc, desc
     with pytest.raises(lib.GpfqError):
-        lib.describe_plan(8, 8, 2_000_000)
+        lib.describe_plan(8, 8, 4_200_000)
 
 
 def test_partition_covers_every_neuron_once():
