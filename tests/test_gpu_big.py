@@ -80,3 +80,37 @@ def test_one_call_entry_point_through_the_integration_stub(oracle_mod, name):
         assert np.array_equal(idx.cpu().numpy().astype(np.int16), fx["idx"])
         assert np.array_equal(Q.cpu().numpy(), fx["Q"])
         assert np.abs(U.cpu().numpy() - fx["U"]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["g2_32x288x1024_msq_b4", "g2_24x96x2500_msq_b4", "g2_8x48x5000_soft_b2", "g3_percentile95_hard",
+                                  "g4_groups4_soft", "g4_depthwise_hard", "g6_256x1152x2048_msq_b4", "g6_128x1152x26624_msq_b4"])
+def test_torch_extension_operator(oracle_mod, name):
+    """torch.ops.gpfq.quantize_layer (the thin PyTorch-ROCm extension over the C ABI): indices / Q / U bit-equal to the
+    oracle and to the reference fixture; strided (m, D) views are taken as they are; the fused sum of squares matches U."""
+    from quantized_neural_nets_amd import torch_ext  # noqa: F401
+    big = name.startswith("g6_")
+    case, (W, A, X), fx, meta = (gi.load_big_case if big else gi.load_case)(name)
+    K = 2 ** (case["bits"] - 1)
+    mode = 1 if case["reg"] == "L1" else 2 if case["reg"] == "L0" else 0
+    Ad, Xd = _t(A), _t(X)
+    if not big:                                         # a view with a leading dimension: columns [0, D) of a wider matrix
+        wide = torch.zeros((A.shape[0], A.shape[1] + 5), device=DEV)
+        wide[:, :A.shape[1]] = Ad
+        Ad = wide[:, :A.shape[1]]
+    Q, idx, U, usq = torch.ops.gpfq.quantize_layer(_t(W), Ad, Xd, float(fx["step"]), K, mode, float(case["lamb"]), case["groups"], 0, 0)
+    torch.cuda.synchronize()
+    o = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"], case["groups"],
+                                  step=float(fx["step"]))
+    assert idx.dtype == torch.int8
+    assert np.array_equal(idx.cpu().numpy().astype(np.int16), o["idx"])
+    assert np.array_equal(U.cpu().numpy(), o["U"]) and np.array_equal(Q.cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
+    assert torch.allclose(usq.double().sum(1), (U.double() ** 2).sum(1), rtol=1e-5)
+    if big:
+        check_big_case(name, dict(idx=idx.cpu().numpy(), U=U.cpu().numpy(), step=float(fx["step"])), "torch.ops.gpfq")
+    else:
+        assert np.array_equal(idx.cpu().numpy().astype(np.int16), fx["idx"]) and np.array_equal(Q.cpu().numpy(), fx["Q"])
+    with pytest.raises(RuntimeError):
+        torch.ops.gpfq.quantize_layer(_t(W), _t(A)[:, :-1], _t(X)[:, :-1], 0.1, K, mode, 0.0, case["groups"], 0, 0)
+    q = torch.ops.gpfq.quantizer(_t(W), float(fx["step"]), K, 0, 0.0, None)
+    qo, _ = oracle_mod.quantizer_vec(0, float(fx["step"]), W, K)
+    assert np.array_equal(q.cpu().numpy().ravel().view(np.uint32), qo.view(np.uint32))

@@ -201,3 +201,17 @@ def test_packed_rebuild_equals_oracle_q(oracle_mod):
         back = packed.unpack_indices(data, nbits, idx.numel(), K, mode).reshape(idx.shape)
         q = dist.rebuild_q(back, float(o["step"]), K, mode, float(case["lamb"] or 0.0))
         assert np.array_equal(q.numpy(), o["Q"])
+
+
+def test_torch_extension_registers_the_operators_and_refuses_cpu_tensors(lib):
+    """The TORCH_LIBRARY(gpfq) extension over the C ABI (level 3): schema as the survey gives it (plus
+    the plan and the fused sum-of-squares output); only the HIP dispatch key exists, so CPU tensors are an error."""
+    from quantized_neural_nets_amd import torch_ext
+    assert os.path.exists(torch_ext.LIB_PATH)
+    schema = str(torch.ops.gpfq.quantize_layer.default._schema)
+    assert schema.startswith("gpfq::quantize_layer(Tensor W, Tensor A, Tensor X, float step, int K, int mode, float lamb, int groups, int seed, int plan)")
+    assert schema.endswith("-> (Tensor, Tensor, Tensor, Tensor)")
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.gpfq.quantize_layer(torch.zeros(4, 4), torch.zeros(8, 4), torch.zeros(8, 4), 0.1, 8, 0, 0.0, 1, 0, 0)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        torch.ops.gpfq.quantizer(torch.zeros(4), 0.1, 8, 0, 0.0, None)
