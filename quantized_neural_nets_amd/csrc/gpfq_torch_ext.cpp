@@ -4,15 +4,16 @@
 //   torch.ops.gpfq.quantizer(x, step, K, mode, lamb, uniform) -> q
 //
 // It owns nothing of the algorithm: argument checks (TORCH_CHECK -> RuntimeError, the convention 8(b) asks for),
-// output allocation with at::empty on the inputs' device, the CURRENT HIP stream, and one call into libgpfq_hip.so
+// output allocation with at::empty on the inputs' device, the CURRENT HIP stream (PyTorch-ROCm presents HIP devices
+// under the "cuda" device type, hence the ...MasqueradingAsCUDA accessor), and one call into libgpfq_hip.so
 // (gpfq_quantize_layer_f32 = StepAlgorithm._quantize_layer's native part, step_algorithm.py:194-196, :212-247;
 // gpfq_quantizer_f32 = the four quantizers, :7-104).  A cooperative launch that gave up waiting for a peer workgroup
 // is redone on GPFQ_PLAN_STREAM_ROWS before anything is returned.  HIP dispatch key only: there is no CPU kernel,
 // CPU tensors are refused.
 // Built by csrc/Makefile with g++ against the torch headers; linked against libgpfq_hip.so ($ORIGIN rpath).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
 #include <tuple>
@@ -53,7 +54,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> quantize_layer(const 
     TORCH_CHECK(mode >= 0 && mode <= 3, "gpfq: mode must be 0 (msq), 1 (soft), 2 (hard) or 3 (stochastic)");
     TORCH_CHECK(K >= 1 && K <= 32766, "gpfq: boundary index K out of range");
     const bool i16 = K > 126;                          // int8 holds K <= 126 (bits <= 7); bits = 8 needs int16
-    c10::hip::HIPGuard guard(W.device());
+    c10::DeviceGuard guard(W.device());
     auto opts = W.options();
     at::Tensor Q = at::empty({N, dg}, opts);
     at::Tensor idx = at::empty({N, dg}, opts.dtype(i16 ? at::kShort : at::kChar));
@@ -66,7 +67,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> quantize_layer(const 
     }
     const size_t wsb = gpfq_workspace_bytes(N, dg, m, (int)groups);
     at::Tensor ws = at::zeros({(int64_t)wsb}, opts.dtype(at::kByte));      // zeroed: its head is the status / exchange scratch
-    void* stream = c10::hip::getCurrentHIPStream(W.device().index()).stream();
+    void* stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(W.device().index()).stream();
     auto run = [&](int p) {
         const int rc = gpfq_quantize_layer_f32(W.data_ptr<float>(), A.data_ptr<float>(), lda, X.data_ptr<float>(), ldx, N, dg, m,
                                                (int)groups, (float)step, (int)K, (int)mode, (float)lamb, (uint64_t)seed, 0,
@@ -88,7 +89,7 @@ at::Tensor quantizer(const at::Tensor& x, double step, int64_t K, int64_t mode, 
 {
     check_cuda_f32(x, "x");
     TORCH_CHECK(mode >= 0 && mode <= 3 && K >= 1, "gpfq: bad mode / K");
-    c10::hip::HIPGuard guard(x.device());
+    c10::DeviceGuard guard(x.device());
     at::Tensor xc = x.contiguous();
     at::Tensor out = at::empty_like(xc);
     const float* un = nullptr;
@@ -101,7 +102,7 @@ at::Tensor quantizer(const at::Tensor& x, double step, int64_t K, int64_t mode, 
     }
     TORCH_CHECK(mode != 3 || un, "gpfq: the stochastic quantizer needs the uniform draws");
     const int rc = gpfq_quantizer_f32((int)mode, (float)step, xc.data_ptr<float>(), xc.numel(), (int)K, (float)lamb, un,
-                                      out.data_ptr<float>(), nullptr, c10::hip::getCurrentHIPStream(x.device().index()).stream());
+                                      out.data_ptr<float>(), nullptr, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(x.device().index()).stream());
     TORCH_CHECK(rc == 0, "gpfq error ", rc, ": ", gpfq_last_error());
     return out.view(x.sizes());
 }
