@@ -296,6 +296,7 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.vec = vec ? 1 : 0;
     sp.step = p.qc.step; sp.Kf = p.qc.Kf; sp.lamb = p.qc.lamb;
     sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
+    sp.pace = env_int("GPFQ_COOP_PACE", 2);
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     return sp;
 }

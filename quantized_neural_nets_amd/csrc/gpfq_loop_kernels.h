@@ -91,6 +91,7 @@ struct SlabParams {
     unsigned long long* xbuf; int* status;
     int64_t ldw, ldq, ldu, ldi, m, m_pad;
     int Ng, d, S, C, tiles, idx_bytes, vec;
+    int pace;          // cooperative kernels: pauses (s_sleep 1 each) between the column requests issued in the exchange window; 0 = off
     float step, Kf, lamb;
     unsigned spin_limit;
     uint64_t seed, row_id0;
@@ -363,6 +364,11 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
 #endif
     int t = 0;
     bool dead = false;
+    // Column requests in the exchange window (below) only when the reducer is a wave of its own: where wave 0 doubles as
+    // the reducer (12 sweep waves) the window requests of the other eleven waves sit in front of its polls and the
+    // exchange gets slower than the sweep phase gets faster (measured per column: 2.17 -> 2.4-2.5 us; with a dedicated
+    // reducer 1.65 -> 1.60 and 2.20 -> 2.12).
+    const bool trickle = p.pace > 0 && NW > max_own;
     // one step; XP holds x_{t-1}, XC x_t, AC a_t.  Returns false after the last column or on a timeout.
     auto step = [&](auto xp_, auto xc_, auto ac_) -> bool {
         constexpr int XP = decltype(xp_)::value, XC = decltype(xc_)::value, AC = decltype(ac_)::value;
@@ -370,13 +376,6 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         const int par = t & 1;
         const bool more = t + 1 < p.d;
         float* seg = segs + par * RT * NW;
-        // next column's weights and norm through the scalar cache; the last step re-reads its own (unused) ones
-        // rather than branch
-        float wn[RT];
-        const int tn = more ? t + 1 : t;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
-        const float n2n = nrm[tn];
         // the pointers advance in every wave (uniform values must not change under a per-wave condition, or they
         // stop being scalar); the last steps re-read the last column rather than branch
         {
@@ -399,27 +398,55 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
                 const float sg = wave_tree64_lane63(acc[r]);
                 if (lane == 63) seg[r * NW + wave] = sg;
             }
-            // the next column wanted into the registers the sweeps have just finished with (x_{t-1}'s and a_t's): three
-            // quarters here, the last one behind barrier 2
-            win_load4<XP, 0>(xload, lane_off);
-            win_load4<AC, 0>(aload, lane_off);
-            win_load4<XP, 1>(xload, lane_off);
-            win_load4<AC, 1>(aload, lane_off);
-            win_load4<XP, 2>(xload, lane_off);
-            win_load4<AC, 2>(aload, lane_off);
+            // The next column wanted goes into the registers the sweeps have just finished with (x_{t-1}'s and a_t's).
+            // A wave that is also the reducer requests three quarters here and the last one behind barrier 2, as in
+            // round 1 (its exchange comes next: the queue must be short by then).  Every other sweep wave waits for the
+            // exchange window below.
+            if (!trickle || wave == rwave) {
+                win_load4<XP, 0>(xload, lane_off);
+                win_load4<AC, 0>(aload, lane_off);
+                win_load4<XP, 1>(xload, lane_off);
+                win_load4<AC, 1>(aload, lane_off);
+                win_load4<XP, 2>(xload, lane_off);
+                win_load4<AC, 2>(aload, lane_off);
+            }
             GPFQ_STAMP(2)
         }
         __syncthreads();
         GPFQ_STAMP(3)
+        // next column's weights and norm through the scalar cache (the last step re-reads its own, unused, ones rather
+        // than branch), requested here: at the top of the step their round trip sat in front of the sweep (scalar loads
+        // and LDS share lgkmcnt, any wait on it waits for all of them); behind barrier 1 the sweep waves have nothing to do
+        float wn[RT];
+        const int tn = more ? t + 1 : t;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
+        const float n2n = nrm[tn];
         if (wave == rwave) {
             GPFQ_STAMP(4)
             reducer_section<RT, MODE>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, row0, grow0, seg_lo);
             GPFQ_STAMP(5)
+        } else if (trickle && active) {
+            // The exchange window: the sweep waves idle here for ~2 000 cycles while the reducer's granules travel.  Their
+            // eight column requests go out NOW, one at a time with a pause between: issued together behind the lane tree
+            // (round 1) they filled the CU's in-order vector-memory queue exactly when every wave wanted to reach barrier
+            // 1 -- 96 requests of 16 clocks each at 12 waves, the waves stalling at issue -- and issued together here they
+            // would sit in front of the reducer's granule store and polls.  Paced, the queue stays a few entries deep.
+            __builtin_amdgcn_s_sleep(2);                                 // the reducer's granule store goes first
+            auto pause = [&]() { for (int i = 0; i < p.pace; ++i) __builtin_amdgcn_s_sleep(1); };
+            win_load4<XP, 0>(xload, lane_off); pause();
+            win_load4<AC, 0>(aload, lane_off); pause();
+            win_load4<XP, 1>(xload, lane_off); pause();
+            win_load4<AC, 1>(aload, lane_off); pause();
+            win_load4<XP, 2>(xload, lane_off); pause();
+            win_load4<AC, 2>(aload, lane_off); pause();
+            win_load4<XP, 3>(xload, lane_off); pause();
+            win_load4<AC, 3>(aload, lane_off);
         }
         GPFQ_STAMP(6)
         __syncthreads();
         GPFQ_STAMP(7)
-        if (active) {
+        if (active && (!trickle || wave == rwave)) {
             win_load4<XP, 3>(xload, lane_off);
             win_load4<AC, 3>(aload, lane_off);
         }

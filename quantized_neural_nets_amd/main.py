@@ -44,6 +44,9 @@ def build_parser():
     # additions of this build
     p.add_argument('--synthetic', action='store_true', help='random calibration batches instead of the dataset loader')
     p.add_argument('--image_size', default=224, type=int, help='side of the synthetic images')
+    p.add_argument('--data_loaders_dir', default=None,
+                   help="directory holding the reference's data_loaders.py (its src/): the dataset loader is imported from "
+                        "exactly there, never from whatever module of that name sys.path happens to offer")
     p.add_argument('--save_dir', default=None, help='where to torch.save the quantized model, as main.py:127-136 does under '
                                                    '../quantized_models/ (default: not saved)')
     p.add_argument('--log_file', default=os.path.join('logs', 'Quantization_Log.csv'),
@@ -144,11 +147,16 @@ def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
     if args.synthetic:
         train_loader = SyntheticLoader(bs, args.image_size, args.seed)
     else:
-        try:
-            from data_loaders import data_loader          # the reference's own loader module, if on the path
-        except ImportError:
-            raise SystemExit("no dataset loader available here: use --synthetic")
-        train_loader, test_loader = data_loader(args.data_set, bs, args.num_worker)
+        if not args.data_loaders_dir:
+            raise SystemExit("no dataset loader: use --synthetic, or --data_loaders_dir <the reference's src/> for its ImageNet loader")
+        import importlib.util
+        path = os.path.join(args.data_loaders_dir, "data_loaders.py")
+        if not os.path.isfile(path):
+            raise SystemExit("no data_loaders.py in %s" % args.data_loaders_dir)
+        spec = importlib.util.spec_from_file_location("gpfq_reference_data_loaders", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)                      # (main.py:10, :80: data_loader(data_set, batch_size, num_worker))
+        train_loader, test_loader = mod.data_loader(args.data_set, bs, args.num_worker)
     quantizer = QuantizeNeuralNet(model, args.model, bs, train_loader, mlp_bits=bits, cnn_bits=bits,
                                   ignore_layers=args.ignore_layer, mlp_alphabet_scalar=mlp_s, cnn_alphabet_scalar=cnn_s,
                                   mlp_percentile=mlp_per, cnn_percentile=cnn_per, reg=args.regularizer, lamb=lamb,

@@ -77,6 +77,17 @@ def test_bench_runs_sharded(tmp_path):
     assert rec["output_check"]["mismatches"] == 0 and rec["output_check"]["layers"] == 1
 
 
+def test_bench_capture_mode_runs():
+    """bench.py --capture: column preparation by the driver's fused patch gather from synthetic feature maps."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--capture", "--steps", "1", "--warmup", "1", "--layers", "layer4.1",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["config"]["column_prep"].startswith("fused patch gather") and rec["output_check"]["mismatches"] == 0
+    assert rec["roofline"]["kernel"] == "gpfq_resident_rt2_m0_w8" and rec["roofline_l2"]["frac"] <= 1.0
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` WITHOUT torchrun (what the driver's scaling run does): bench.py starts
     torch.distributed.run itself as a child process before touching the GPU, relays the JSON line and the exit code."""
