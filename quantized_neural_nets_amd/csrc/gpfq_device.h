@@ -43,21 +43,9 @@ __device__ __forceinline__ float xor32_add(float v)
     return a + b;
 }
 
-// Balanced pairwise tree over the 64 lanes, result in every lane: ((v0+v1)+(v2+v3))+... exactly the
-// oracle's tree64 (every level adds the two halves of an aligned block; fp add is commutative, so the
-// mirror / swap forms give the same bits as the xor butterfly).  Needs EXEC = all lanes.
-__device__ __forceinline__ float wave_tree64(float v)
-{
-    v = v + dpp_mov<0xB1>(v);     // l ^ 1
-    v = v + dpp_mov<0x4E>(v);     // l ^ 2
-    v = v + dpp_mov<0x141>(v);    // other quad of the 8-group (quads are uniform by now)
-    v = v + dpp_mov<0x140>(v);    // other 8-group of the row
-    v = xor16_add(v);
-    v = xor32_add(v);
-    return v;
-}
-
-// Same tree, total delivered in lane 63 only, all six levels as DPP adds (no permlane swap, no extra moves):
+// Balanced pairwise tree over the 64 lanes, ((v0+v1)+(v2+v3))+... exactly the oracle's tree64 (every level adds the two
+// halves of an aligned block; fp add is commutative, so the mirror forms give the same bits as an xor butterfly), total
+// delivered in lane 63 only, all six levels as DPP adds (no permlane swap, no extra moves).  Needs EXEC = all lanes.
 // after the four in-row levels every lane of a row holds its row sum; row_bcast15 adds lane 15 of the previous
 // row into rows 1 and 3 (r1+r0, r3+r2), row_bcast31 adds lane 31 (= r1+r0) into rows 2 and 3, so row 3 ends with
 // (r3+r2)+(r1+r0): the canonical tree up to operand order.  Disabled rows add the +0.0f of `old`.
@@ -192,15 +180,6 @@ __device__ __forceinline__ float combine_slots(const float* seg, const SlotMap m
     case 64: if constexpr (BIG) v = block_tree_seq<64>(seg, mp, s_last); else v = 0.0f; break;
     default: v = block_tree<1>(seg, mp, s_last); break;
     }
-    v = wave_tree_n(v, nl);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-
-// combine_slots for blocks of at most 64 slots (one slot per lane): no switch, no per-slot loop
-__device__ __forceinline__ float combine_slots1(const float* seg, const SlotMap mp, int nl)
-{
-    const float val = seg[mp.s0];
-    float v = (mp.mask & 1u) ? val : 0.0f;
     v = wave_tree_n(v, nl);
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
@@ -342,99 +321,6 @@ __device__ __forceinline__ void load16(float (&dst)[16], const float* __restrict
         float4 v = *reinterpret_cast<const float4*>(p + 256 * c);
         dst[4 * c + 0] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
     }
-}
-
-// ---- column loads whose landing is waited for by hand ---------------------------------------------
-// The register-resident kernels keep the loads of column t+2 in flight across a whole step.  LLVM's vmcnt
-// bookkeeping degrades to vmcnt(0) as soon as the loop body has internal control flow (roles, poll loops, the
-// residual's final store), which serialises every sweep behind the loads issued just before it.  So these loads
-// are inline asm -- invisible to the compiler's counters -- and the consumer waits with an explicit
-// s_waitcnt vmcnt(N) that takes the registers as read-write operands, so that no use can be scheduled above it.
-// Rules that keep this sound:
-//  * a Col16 written by load16_async is not read by anything before wait_landed<N>() names it;
-//  * N counts only the asm loads issued after the wanted ones; vector-memory instructions the compiler knows
-//    about (the Q / idx history stores, the exchange granules) only make a wait stricter, never looser, because
-//    the counter retires in order;
-//  * the kernels that use this must not spill (a spill of an in-flight register would store stale data): the
-//    Makefile's `asm` target prints the spill counts, and tools/check_async_loads.py scans the ISA for copies.
-typedef float v4f __attribute__((ext_vector_type(4)));
-struct Col16 {
-    v4f v[4];                                   // element e = 4*c + j  <->  v[c][j]
-};
-
-__device__ __forceinline__ void zero16(Col16& d)
-{
-#pragma unroll
-    for (int c = 0; c < 4; ++c) d.v[c] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-}
-
-// base: wave-uniform column pointer (an SGPR pair), lane_off: this lane's byte offset inside the segment (16 * lane).
-// The destination is a read-write operand although nothing is read: that ties the new value to the register of
-// the old one, so a buffer keeps its registers around the unrolled loop and no copy of it is ever needed at the
-// back edge (a copy there would read registers whose loads are still in flight).
-__device__ __forceinline__ void load16_async(Col16& d, const float* base, unsigned lane_off)
-{
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(d.v[0]) : "v"(lane_off), "s"(base));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(d.v[1]) : "v"(lane_off), "s"(base));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(d.v[2]) : "v"(lane_off), "s"(base));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "+v"(d.v[3]) : "v"(lane_off), "s"(base));
-}
-
-// one quarter (chunk Q: 4 of the 16 elements) of the same loads, for kernels that spread a column's requests over
-// the step instead of queueing eight at once
-template <int Q>
-__device__ __forceinline__ void load4_async(Col16& d, const float* base, unsigned lane_off)
-{
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d.v[Q]) : "v"(lane_off), "s"(base), "n"(1024 * Q));
-}
-
-// the same loads left to the compiler (its own s_waitcnt, safe under register spills): for the one variant that
-// has no room for the look-ahead buffers and spills
-__device__ __forceinline__ void load16_sync(Col16& d, const float* base, unsigned lane_off)
-{
-    const char* q = reinterpret_cast<const char*>(base) + lane_off;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) d.v[c] = *reinterpret_cast<const v4f*>(q + 1024 * c);
-}
-
-// Wait until at most N of this wave's vector-memory operations are outstanding; a and b are usable afterwards.
-// Three parts: the hardware wait; a scheduling barrier, so that nothing -- in particular no register copy that
-// feeds the next statement -- is placed above the wait; and an empty asm that takes the registers as read-write
-// operands, so that every later use depends on it.
-template <int N>
-__device__ __forceinline__ void wait_landed(Col16& a, Col16& b)
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]),
-                 "+v"(b.v[3]));
-}
-template <int N>
-__device__ __forceinline__ void wait_landed(Col16& a)
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]));
-}
-
-// sweep16 on Col16 operands (same operations, same order)
-template <bool SUB>
-__device__ __forceinline__ float sweep16(float (&u)[16], const Col16& xp, const Col16& a, const Col16& x, float qprev, float w)
-{
-    float acc = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float uu = u[e];
-        if (SUB) {
-            float p = qprev * xp.v[e >> 2][e & 3];
-            uu = uu - p;
-        }
-        float pa = w * a.v[e >> 2][e & 3];
-        uu = uu + pa;
-        u[e] = uu;
-        acc = __builtin_fmaf(uu, x.v[e >> 2][e & 3], acc);
-    }
-    return acc;
 }
 
 // ---- the column window: physical registers the compiler never sees --------------------------------------------

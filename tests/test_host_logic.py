@@ -215,3 +215,33 @@ def test_torch_extension_registers_the_operators_and_refuses_cpu_tensors(lib):
         torch.ops.gpfq.quantize_layer(torch.zeros(4, 4), torch.zeros(8, 4), torch.zeros(8, 4), 0.1, 8, 0, 0.0, 1, 0, 0)
     with pytest.raises((RuntimeError, NotImplementedError)):
         torch.ops.gpfq.quantizer(torch.zeros(4), 0.1, 8, 0, 0.0, None)
+
+
+def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed rocprofv3 PMC summary ONLY if that summary carries the digest of the kernel
+    sources the run was built from (tools/pmc_traffic.py stamps it); a summary of other sources yields null, not stale bytes."""
+    import json
+    import bench
+    from quantized_neural_nets_amd import _lib
+    digest = _lib.kernel_source_digest()
+    assert len(digest) == 64 and digest == _lib.kernel_source_digest()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    kern = {"void gpfq::gpfq_resident_rt2_m0_w8(gpfq::SlabParams)": {"launches": 6, "hbm_bytes_per_launch": 123}}
+    (prof / "r99_a_pmc_traffic.json").write_text(json.dumps({"source_sha256": "0" * 64, "kernels": kern}))
+    got, src = bench.pmc_traffic("gpfq_resident_rt2_m0_w8", digest)
+    assert got is None and "no PMC summary for this kernel source" in src
+    (prof / "r99_b_pmc_traffic.json").write_text(json.dumps({"source_sha256": digest, "kernels": kern}))
+    got, src = bench.pmc_traffic("gpfq_resident_rt2_m0_w8", digest)
+    assert got == 123 and src.endswith("r99_b_pmc_traffic.json")
+    # and the committed summary of this round matches the committed sources, kernel names included
+    real = json.load(open(os.path.join(ROOT, "profiles", "r02_v2_pmc_traffic.json")))
+    assert real["source_sha256"] == digest, "profiles/r02_v2_pmc_traffic.json was collected on other kernel sources: re-collect"
+    assert any("gpfq_resident_rt2_m0_w8" in k for k in real["kernels"]) and any("gpfq_coop_rt4_m0_w12" in k for k in real["kernels"])
+    # the kernel names bench.py derives from a plan description are the names rocprofv3 reports
+    assert bench.kernel_name("resident RT=2 waves=7 S=7 grid=(256,1) d=4608") == "gpfq_resident_rt2_m0_w8"
+    assert bench.kernel_name("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == "gpfq_coop_rt4_m0_w12"
+    assert bench.kernel_name("coop RT=2 C=4 waves=7 S=26 grid=256 d=1152", 1) == "gpfq_coop_rt2_m1_w8"
+    assert bench.l2_column_bytes("resident RT=2 waves=7 S=7 grid=(256,1) d=4608", 512, 4608, 7168) == 256 * 4608 * 8 * 7168
+    assert bench.l2_column_bytes("stream RT=4 waves=8 S=50 grid=(320,1) d=320", 1280, 320, 51200) is None

@@ -32,6 +32,9 @@ def main():
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
         elif fam == "resident":
             N, m = int(rng.integers(1, 40)), int(rng.integers(1025, 16385))
+            # rows per workgroup: forced, so that the 2- and 4-row kernels (chosen on their own only from 512 rows on) and
+            # their ragged last tiles are covered at sizes the oracle finishes quickly
+            os.environ["GPFQ_RESIDENT_RT"] = str(int(rng.choice([1, 2, 4])))
         elif fam == "coop":
             N, m = int(rng.integers(1, 24)), int(rng.integers(16385, 60000))
         elif fam == "coop_rows":                    # enough rows for the 2- and 4-row cooperative variants
@@ -55,12 +58,14 @@ def main():
                                              dev, compute_errors=False, plan=plan)
         torch.cuda.synchronize()
         _lib.check_status(dev)
+        os.environ.pop("GPFQ_RESIDENT_RT", None)
         o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
         desc = _lib.describe_plan(N, d, m, groups, plan).split()[0]
         kinds[desc] = kinds.get(desc, 0) + 1
         ok = (np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
               and np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
-              and np.array_equal(r["U"].cpu().numpy(), o["U"]))
+              and np.array_equal(r["U"].cpu().numpy(), o["U"])
+              and torch.allclose(r["usq_seg"].double().sum(1), (r["U"].double() ** 2).sum(1), rtol=1e-5, atol=1e-30))
         if not ok:
             bad += 1
             print("MISMATCH", case, desc, flush=True)
