@@ -48,6 +48,8 @@ struct Plan {
     int S;         // segments per row
     int C;         // coop: members per row tile
     int tiles;     // coop: row tiles
+    int rounds;    // coop: launches the rows are spread over (every launch must be co-resident); 1 = all rows at once
+    int tiles_round;   // coop: row tiles per launch
 };
 
 int device_cu_count()
@@ -72,6 +74,21 @@ int env_int(const char* name, int dflt)
 int slab_max_waves(bool coop, int RT);
 int resident_max_rt(int waves);
 
+// wave bound of the cooperative kernel variant that takes NW sweep waves of RT rows (keep coop_kernel() in step)
+int coop_wave_bound(int RT, int NW)
+{
+    if (RT == 1) return 12;
+    if (NW <= 8) return 8;
+    return (NW <= 12 || RT != 2) ? 12 : 16;
+}
+
+int pow2_ceil_host(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
 // Cost model of one cooperative column step (microseconds): least squares over 50 measured (N, S, RT, C) points on an
 // MI355X (tools/layer_bench.py sweep over the ResNet-50 cooperative shapes and their 2-, 4- and 8-way row shards; rms
 // error 0.18 us, and it picks the fastest measured configuration for every one of those shapes).  A fixed part
@@ -82,7 +99,7 @@ double slab_step_cost(int RT, int waves, int C, int wgs)
 {
     const int n = RT * C;
     return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.28 + 1.02 * wgs / 256.0 : 0.0) + (C >= 32 ? 0.65 : 0.0) +
-           (C >= 64 ? 1.5 : 0.0) + ((RT == 4 && waves > 8) ? 0.43 : 0.0);
+           (C >= 64 ? 1.5 : 0.0) + (((RT == 4 && waves > 8) || (RT == 2 && waves > 12)) ? 0.43 : 0.0);
 }
 
 // Rows per workgroup of the resident plan: the rows of a workgroup share every column load, and the CU's vector-memory
@@ -117,36 +134,52 @@ double resident_step_cost(int64_t Ng, int S, int cus)
     return (double)rounds * (0.25 + pipe + 0.18 * (RT - 1));
 }
 
-// Cooperative configuration: cheapest modelled step among the (RT, C) pairs whose grid is co-resident.
-// Depends on (Ng, S, CU count) only -- never on the data.
-bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullptr)
+// What one column costs on the streaming plan (microseconds; measured on the ResNet-50 1x1 convolutions at batch
+// 1024, profiles/r02_v1_bench_r50_all_layers.txt: 4.7-5.5 TB/s of algorithmic bytes, 6.3 when the residual fits the
+// Infinity Cache and whole rows cover the chip).
+double stream_col_cost(int64_t Ng, int S, int cus)
+{
+    const double bytes = 8.0 * (double)Ng * S * 4096.0 / 4.0;
+    const bool cached = (double)Ng * S * 4096.0 <= 220e6 && Ng >= 4 * (int64_t)cus;
+    return bytes / (cached ? 6.3e6 : 5.0e6);
+}
+
+// Cooperative configuration: cheapest modelled layer among the (RT, C) pairs.  A grid that is not co-resident as a
+// whole runs in ROUNDS: rows are independent, so the layer is cut into blocks of rows whose workgroups all fit on the
+// chip, one launch per block, every launch walking all d columns with its block of U in registers (the columns come
+// from L2 / the Infinity Cache again; U, the 8*N*m bytes per column of the streaming plan, never moves).
+// Depends on (Ng, S, CU count) only -- never on the data.  cost_out: microseconds per column for all rows.
+bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullptr, bool allow_rounds = true)
 {
     const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
     const int wgs_per_cu = env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1;
     const int capacity = cus * wgs_per_cu;
+    if (env_int("GPFQ_COOP_NO_ROUNDS", 0)) allow_rounds = false;
     double best = 1e30;
     bool found = false;
     for (int RT = 4; RT >= 1; RT >>= 1) {
         if (force_rt && RT != force_rt) continue;
         const int64_t tiles = (Ng + RT - 1) / RT;
-        if (tiles > capacity) continue;
-        for (int C = 64 / RT; C >= 2; C >>= 1) {
+        for (int C = 128 / RT; C >= 2; C >>= 1) {                    // the reducer gathers RT * C <= 128 granules
             if (force_c && C != force_c) continue;
-            if (C > S || tiles * C > capacity) continue;
+            if (C > S || C > capacity) continue;
             const int NW = (S + C - 1) / C;
-            if (NW > slab_max_waves(true, RT)) continue;
-            const int wgs = (int)tiles * C;
+            if (NW > slab_max_waves(true, RT) || pow2_ceil_host(S) / C > 16) continue;
+            const int64_t tiles_round = tiles * C <= capacity ? tiles : capacity / C;
+            const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
+            if (rounds > 1 && !allow_rounds) continue;
+            const int wgs = (int)tiles_round * C;
             const int per_cu = (wgs + cus - 1) / cus;
             if ((per_cu * NW + 3) / 4 > 4) continue;
-            // rounds of work if the grid does not cover the chip are not modelled: fewer workgroups than CUs
-            // simply leave CUs idle, which costs nothing per step
-            const int vmax = RT == 1 ? 12 : (NW <= 8 ? 8 : 12);      // wave bound of the variant launch_slab picks
+            // fewer workgroups than CUs simply leave CUs idle, which costs nothing per step
+            const int vmax = coop_wave_bound(RT, NW);                // wave bound of the variant launch_slab picks
             const int launched = NW + (NW + 1 <= vmax ? 1 : 0);      // + the reducer wave when it fits
-            double cost = slab_step_cost(RT, per_cu * launched, C, wgs);
+            const double cost = (double)rounds * slab_step_cost(RT, per_cu * launched, C, wgs);
             if (!found || cost < best - 1e-9) {
                 found = true;
                 best = cost;
                 pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
+                pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round;
             }
         }
     }
@@ -163,6 +196,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
     pl->kind = GPFQ_PLAN_STREAM;
     pl->S = S;
     pl->C = 1;
+    pl->rounds = 1; pl->tiles_round = 0;
     pl->RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
     while (pl->RT > 1 && (size_t)2 * pl->RT * S * sizeof(float) > 48 * 1024) pl->RT >>= 1;   // the segment sums of RT rows live in LDS
     if (S > 1024 && pl->RT > 2) pl->RT = 2;               // (the four-row kernel has no 32 / 64-slots-per-lane tree)
@@ -203,7 +237,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
 int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, Plan* out)
 {
     Plan pl;
-    pl.C = 1; pl.tiles = 0;
+    pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0;
     if (m_pad / gpfq::kSeg > 4096) return fail(GPFQ_ERR_UNSUPPORTED, "m > 4194304 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
     if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_STREAM_ROWS) return fail(GPFQ_ERR_ARG, "unknown plan id");
@@ -224,7 +258,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
         if (requested == GPFQ_PLAN_AUTO && groups == 1 && have_scratch && Ng > cus && !env_int("GPFQ_COOP_DISABLE", 0)) {
             Plan cp = pl;
             double ccost = 0.0;
-            if (choose_coop(Ng, pl.S, cus, &cp, &ccost) && ccost < 0.97 * resident_step_cost(Ng, pl.S, cus)) {
+            if (choose_coop(Ng, pl.S, cus, &cp, &ccost, false) && ccost < 0.97 * resident_step_cost(Ng, pl.S, cus)) {
                 *out = cp;
                 return GPFQ_OK;
             }
@@ -233,9 +267,14 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
         return GPFQ_OK;
     }
     if (requested == GPFQ_PLAN_COOP || (requested == GPFQ_PLAN_AUTO && !env_int("GPFQ_COOP_DISABLE", 0))) {
-        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, &pl)) {
-            *out = pl;
-            return GPFQ_OK;
+        double ccost = 0.0;
+        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, &pl, &ccost)) {
+            // in rounds only where that beats moving U through memory every column
+            if (pl.rounds == 1 || requested == GPFQ_PLAN_COOP || ccost < 0.9 * stream_col_cost(Ng, pl.S, cus)) {
+                *out = pl;
+                return GPFQ_OK;
+            }
+            pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0;
         }
         if (requested == GPFQ_PLAN_COOP)
             return fail(GPFQ_ERR_UNSUPPORTED, "cooperative plan needs groups == 1, a scratch buffer and a shape that fits");
@@ -315,7 +354,7 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
         default: return gpfq::gpfq_coop_rt##RTV##_m0_w##MAXWV;                                                        \
         }                                                                                                             \
     }
-    GPFQ_PICK(1, 12) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(4, 8)
+    GPFQ_PICK(1, 12) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(2, 16) GPFQ_PICK(4, 8)
 #undef GPFQ_PICK
     if (RT == 4 && maxw == 12) {                    // (no stochastic variant: see GPFQ_DEFINE_COOP in gpfq_loop_kernels.h)
         switch (mode) {
@@ -331,7 +370,7 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
     const int RT = pl.RT;
-    const int maxw = (RT == 1 || pl.waves > 8) ? 12 : 8;
+    const int maxw = coop_wave_bound(RT, pl.waves);
     SlabKernel kern = coop_kernel(RT, mode, maxw);
     if (!kern || pl.waves > maxw) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
     // one more wave for the reducer role when the variant's wave bound allows it
@@ -435,7 +474,7 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
 int slab_max_waves(bool coop, int RT)
 {
     if (!coop) return 16;
-    return 12;
+    return RT == 2 ? 16 : 12;
 }
 
 int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scratch_bytes, hipStream_t st)
@@ -456,7 +495,25 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     p.S = pl.S;
     const bool vec = ((p.ldu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.U) & 15) == 0);
     if (pl.kind == GPFQ_PLAN_COOP) {
-        rc = launch_slab(pl, p, groups, vec, scratch, st);
+        if (pl.rounds <= 1) {
+            rc = launch_slab(pl, p, groups, vec, scratch, st);
+        } else {
+            // one launch per block of rows; a launch that finds the status word raised by an earlier one returns at once
+            const int64_t block = (int64_t)pl.tiles_round * pl.RT;
+            rc = GPFQ_OK;
+            for (int64_t r0 = 0; r0 < p.Ng && rc == GPFQ_OK; r0 += block) {
+                gpfq::LoopParams q = p;
+                Plan pr = pl;
+                q.Ng = (p.Ng - r0 < block) ? p.Ng - r0 : block;
+                pr.tiles = (int)((q.Ng + pl.RT - 1) / pl.RT);
+                q.W = p.W + r0 * p.ldw; q.Q = p.Q + r0 * p.ldq; q.U = p.U + r0 * p.ldu;
+                if (p.idx) q.idx = static_cast<char*>(p.idx) + r0 * p.ldi * p.idx_bytes;
+                if (p.usq) q.usq = p.usq + r0 * pl.S;
+                q.row_id0 = p.row_id0 + (uint64_t)r0;
+                rc = launch_slab(pr, q, groups, vec, scratch, st);
+                if (rc == GPFQ_ERR_UNSUPPORTED && r0 > 0) return fail(GPFQ_ERR_HIP, "internal: a later round of a cooperative layer did not fit");
+            }
+        }
         if (rc == GPFQ_OK) g_used_exchange = 1;
         if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
         rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, &pl);   // does not fit: stream instead
@@ -700,7 +757,10 @@ int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, 
     int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, &pl);
     if (rc) return rc;
     if (buf && buf_bytes) {
-        if (pl.kind == GPFQ_PLAN_COOP)
+        if (pl.kind == GPFQ_PLAN_COOP && pl.rounds > 1)
+            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d rounds=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
+                     pl.tiles_round * pl.C, pl.rounds, (long long)d_g);
+        else if (pl.kind == GPFQ_PLAN_COOP)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
                      pl.tiles * pl.C, (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_STREAM && pl.C > 1)

@@ -111,7 +111,7 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 // lanes, hand q back through LDS and write Q / idx.
 // Lane layout: every row owns an aligned block of lanes padded with +0.0f -- 16 lanes (one DPP row) for the member's
 // own slots (nl <= 16 of them: a member has at most 12 segments), `stride` = max(16, C) lanes for the gathered
-// members -- so that both trees run all their levels without testing how many are needed: a taken branch costs
+// members (max(16, C/2) when RT * C > 64) -- so that both trees run all their levels without testing how many are needed: a taken branch costs
 // ~20 cycles on this chain, and adding +0.0f is exact (a partial sum is never -0.0f, see wave_tree16_zero_padded).
 // Returns whether the exchange timed out (wave-uniform; the same fact is left in the abort word of qs for the other waves).
 template <int RT, int MODE>
@@ -128,7 +128,12 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         v = wave_tree16_zero_padded(((smap.mask & 1u) && r16 < RT) ? val : 0.0f);
     }
     bool timed_out = false;
-    const int sh = C <= 16 ? 4 : (C <= 32 ? 5 : 6);          // log2 of the lane stride of a row in the gather
+    // Gather layout: lane = stride * row + member.  More than 64 granules (RT * C <= 128: long rows that run in rounds)
+    // are gathered two members per lane, 2j and 2j+1 -- adjacent member blocks, the pair the first level of the tree
+    // over the members adds anyway.
+    const bool wide = RT * C > 64;
+    const int per_row = wide ? C >> 1 : C;                    // lanes per row
+    const int sh = per_row <= 16 ? 4 : (per_row <= 32 ? 5 : 6);   // log2 of the lane stride of a row in the gather
     const int gr_ = lane >> sh;              // row of this lane
     const int member = lane & ((1 << sh) - 1);
     {
@@ -138,20 +143,33 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
             __hip_atomic_store(xb_ + (size_t)c * RT + (lane >> 4),
                                ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // gather: lane = stride * row + member
-        const bool want = member < C && gr_ < RT;
-        const unsigned long long* src = xb_ + (want ? (size_t)member * RT + gr_ : 0);
-        unsigned long long gv = 0;
+        const bool want = member < per_row && gr_ < RT;
+        const unsigned long long* src = xb_ + (want ? (size_t)(wide ? 2 * member : member) * RT + gr_ : 0);
+        unsigned long long gv = 0, gw = 0;
         unsigned spins = 0;
-        for (;;) {
-            gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool ok = !want || ((unsigned)(gv >> 32) == epoch);
-            if (__all(ok)) break;
-            if (++spins > p.spin_limit) { timed_out = true; break; }
-            __builtin_amdgcn_s_sleep(1);
+        if (!wide) {
+            for (;;) {
+                gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = !want || ((unsigned)(gv >> 32) == epoch);
+                if (__all(ok)) break;
+                if (++spins > p.spin_limit) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            v = want ? __uint_as_float((unsigned)gv) : 0.0f;
+        } else {
+            const unsigned long long* src1 = src + (want ? RT : 0);
+            for (;;) {
+                gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gw = __hip_atomic_load(src1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = !want || ((unsigned)(gv >> 32) == epoch && (unsigned)(gw >> 32) == epoch);
+                if (__all(ok)) break;
+                if (++spins > p.spin_limit) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            v = want ? __uint_as_float((unsigned)gv) + __uint_as_float((unsigned)gw) : 0.0f;
         }
         // upper levels of the slot tree over the members of each row
-        v = wave_tree16_zero_padded(want ? __uint_as_float((unsigned)gv) : 0.0f);
+        v = wave_tree16_zero_padded(v);
         if (sh > 4) v = xor16_add(v);
         if (sh > 5) v = xor32_add(v);
     }
@@ -275,6 +293,9 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int S = p.S, C = p.C;
     const int P = pow2_ceil(S);
+    // A layer that runs in rounds (one launch per block of rows) stops at the first launch whose exchange timed out: the
+    // status word stays raised until the host has read it, and the layer is redone on another plan anyway.
+    if (*static_cast<volatile const int*>(p.status) != 0) return;
     int tile, c;
     // keep the members of one row tile on one XCD when the tile count allows it (blocks b and b+8 share an
     // XCD under round-robin dispatch; speed only, never correctness)
@@ -519,6 +540,9 @@ GPFQ_DEFINE_COOP_MODES(4, 8, 2, 112, "v255")       // 256 - 80 - 64
 // 168 - 48 - 64: three column buffers, one step of look-ahead.  No stochastic variant: the Philox rounds do not fit
 // the 56 registers left (two would spill); the host streams that combination instead (launch_coop -> UNSUPPORTED).
 GPFQ_DEFINE_COOP(4, 0, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 1, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 2, 12, 1, 56, "v167")
+// 128 - 48 - 32: two rows at 13..16 waves, for rows whose members would otherwise need a 13th sweep wave (P / C = 16 slots
+// per member and S / C just above 12: m = 803 840 is 785 segments, 12.3 per member at C = 64), one step of look-ahead.
+GPFQ_DEFINE_COOP_MODES(2, 16, 1, 48, "v127")
 
 // ------------------------------------------------------------------------------------------------
 // Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE

@@ -1,0 +1,105 @@
+"""Long rows with more rows than the chip holds at once: the cooperative plan in ROUNDS (one co-resident launch per block
+of rows, the residual of the block in registers for all d columns) against the CPU oracle and against the streaming
+plan, bit for bit -- including the gather of more than 64 granules (two members per lane) and the two-row 16-wave
+variant that m = 803 840 (785 segments, 12.3 per member at 64 members) needs.  Shapes are the 1x1 convolutions of
+ResNet-50 / EfficientNet-B1 / VGG-16 at their calibration batches (BASELINE.json configs 2-4) with d cut short."""
+import numpy as np
+import pytest
+import torch
+
+import bench_workload as bw
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(W, A, X, m, plan, mode="msq", seed=None, K=8, step=None):
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    reg = {"msq": None, "soft": "L1", "hard": "L0"}.get(mode)
+    r = SA._quantize_layer_ex(W.to(DEV), A.to(DEV), X.to(DEV), m, 1.16 / 8, K, 1, reg, 0.05, 1, mode == "stochastic",
+                              torch.device(DEV), step_override=step, plan=plan, seed=seed, compute_errors=False)
+    torch.cuda.synchronize()
+    assert r["timeouts"] == []
+    return r
+
+
+# (N, d, m), forced configuration ({} = what AUTO picks), the plan that must result, what the case is there for
+CASES = [
+    ((300, 24, 51200), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "8"}, "coop RT=4 C=8 waves=7 S=50 grid=256 rounds=3",
+     "three rounds, the last one partial (44 rows)"),
+    ((300, 24, 51200), {}, "coop RT=2 C=4 waves=13 S=50 grid=256 rounds=3", "two rows x 13 sweep waves: the 16-wave variant"),
+    ((70, 16, 201728), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "32"}, "coop RT=4 C=32 waves=7 S=197 grid=256 rounds=3",
+     "128 granules: two gathered members per lane; the last tile has 2 valid rows"),
+    ((21, 10, 803840), {}, "coop RT=2 C=64 waves=13 S=785 grid=256 rounds=3", "16-wave variant AND 128 granules, odd row count"),
+    ((20, 10, 720384), {}, "coop RT=2 C=64 waves=11 S=704 grid=256 rounds=3", "128 granules at 64 members (VGG-16 conv1 rows)"),
+    ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
+]
+
+
+@pytest.mark.parametrize("shape,env,plan_desc,why", CASES, ids=["%s_S%d" % (c[2].split(" waves")[0].replace(" ", "_"), c[0][2] // 1024) for c in CASES])
+def test_rounds_equal_oracle_and_streaming(oracle_mod, monkeypatch, shape, env, plan_desc, why):
+    from quantized_neural_nets_amd import _lib
+    N, d, m = shape
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    assert _lib.describe_plan(N, d, m).startswith(plan_desc), _lib.describe_plan(N, d, m)
+    W, A, X = bw.synthetic_layer(N, d, m, 777 + N, first_layer=False)
+    step = bw.layer_step(W)
+    r = _run(W, A, X, m, 0, step=step)
+    Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8)
+    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
+    assert np.array_equal(r["Q"].cpu().numpy(), Q)
+    assert np.array_equal(r["U"].cpu().numpy(), U)
+    st = _run(W, A, X, m, 1, step=step)
+    assert torch.equal(st["idx"], r["idx"]) and torch.equal(st["U"], r["U"]) and torch.equal(st["usq_seg"], r["usq_seg"])
+    ref = (r["U"].double() ** 2).sum(1)
+    assert torch.allclose(r["usq_seg"].double().sum(1), ref, rtol=1e-5)       # the epilogue's rows land at their own offsets
+
+
+@pytest.mark.parametrize("mode", ["soft", "hard", "stochastic"])
+def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, mode):
+    """The other three quantizers through rounds (the 16-wave two-row variant and the four-row one); the stochastic
+    quantizer's Philox key is the GLOBAL row number, so the rows of a later round must not repeat the first round's
+    draws: equality with the oracle (keyed by global rows) and with the streaming plan shows it."""
+    from quantized_neural_nets_amd import _lib
+    omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
+    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200)):
+        assert "rounds=" in _lib.describe_plan(N, d, m)
+        W, A, X = bw.synthetic_layer(N, d, m, 91 + N, first_layer=False)
+        step = bw.layer_step(W)
+        r = _run(W, A, X, m, 0, mode=mode, seed=4321, step=step)
+        Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8, mode=omode, lamb=0.05, seed=4321)
+        assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
+        assert np.array_equal(r["U"].cpu().numpy(), U)
+        st = _run(W, A, X, m, 1, mode=mode, seed=4321, step=step)
+        assert torch.equal(st["idx"], r["idx"]) and torch.equal(st["U"], r["U"])
+
+
+def test_rounds_int16_indices_and_row_shard():
+    """8-bit alphabets store int16 indices (the round's index pointer advances in bytes), and quantizing a block of rows
+    alone gives the slice of the full result whatever the round boundaries are (the neuron-shard property)."""
+    N, d, m = 300, 12, 51200
+    W, A, X = bw.synthetic_layer(N, d, m, 5150, first_layer=False)
+    step = bw.layer_step(W) / 16.0
+    full = _run(W, A, X, m, 0, K=128, step=step)
+    assert full["idx"].dtype == torch.int16 and int(full["idx"].abs().max()) > 8
+    st = _run(W, A, X, m, 1, K=128, step=step)
+    assert torch.equal(st["idx"], full["idx"]) and torch.equal(st["U"], full["U"])
+    part = _run(W[101:259].contiguous(), A, X, m, 0, K=128, step=step)
+    assert torch.equal(part["idx"], full["idx"][101:259]) and torch.equal(part["U"], full["U"][101:259])
+
+
+def test_rounds_stop_after_a_timeout_and_the_layer_is_redone(monkeypatch):
+    """A spin limit of 0 makes the first round's exchange give up; the later rounds must return at once (status word
+    raised), and the driver-level entry redoes the layer on the whole-row streaming plan: same bits as streaming."""
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    N, d, m = 300, 8, 51200
+    W, A, X = bw.synthetic_layer(N, d, m, 616, first_layer=False)
+    step = bw.layer_step(W)
+    ref = _run(W, A, X, m, 1, step=step)
+    monkeypatch.setenv("GPFQ_COOP_SPIN_LIMIT", "0")
+    r = SA._quantize_layer_ex(W.to(DEV), A.to(DEV), X.to(DEV), m, 1.16 / 8, 8, 1, None, 0.05, 1, False,
+                              torch.device(DEV), step_override=step, plan=0, compute_errors=False)
+    torch.cuda.synchronize()
+    assert r["timeouts"], "the forced timeout was not reported"
+    assert torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"])

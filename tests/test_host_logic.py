@@ -71,6 +71,12 @@ def test_plan_selection(lib):
     assert lib.describe_plan(32, 2304, 26624).startswith("coop RT=1 C=8 waves=4")       # an 8-GPU shard of 256 rows
     assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=4 C=2 waves=7")      # long rows, more rows than CUs
     assert lib.describe_plan(64, 9, 30000, 64).startswith("stream")                     # grouped: never cooperative
+    # long rows, more of them than the chip holds: cooperative in rounds (one co-resident launch per block of rows)
+    assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=2 C=4 waves=13 S=50 grid=256 rounds=16")
+    assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=32 waves=7 S=197 grid=256 rounds=32")   # 128 granules
+    assert lib.describe_plan(256, 64, 803840).startswith("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32")    # 16-wave variant
+    assert lib.describe_plan(2048, 512, 13312).startswith("resident RT=1 waves=13")     # <= 16 segments: whole rows, no exchange
+    assert lib.describe_plan(16, 32, 3212288).startswith("stream")                      # 3137 segments: beyond 128 granules x 12
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
     # the fallback plan: whole rows per workgroup, never an exchange, whatever the shape
     for shape in ((64, 576, 93184), (8, 576, 93184), (512, 4608, 3072), (256, 2304, 803840)):
