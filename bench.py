@@ -157,8 +157,15 @@ def kernel_name(desc, mode=0):
             return "gpfq_wave_kernel<"
         return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
-        return "gpfq_coop_rt%d_m%d_w%d" % (rt, mode, 12 if (rt == 1 or waves > 8) else 8)
+        return "gpfq_coop_rt%d_m%d_w%d" % (rt, mode, 12 if rt == 1 else 8 if waves <= 8 else 16 if (rt == 2 and waves > 12) else 12)
     return "gpfq_stream_kernel<%d, true" % rt
+
+
+def plan_rounds(desc):
+    """Launches a layer's loop is spread over: a cooperative plan whose workgroups do not all fit on the chip runs one
+    co-resident launch per block of rows (quantized_neural_nets_amd/csrc run_loop)."""
+    kv = dict(x.split("=") for x in desc.split()[1:] if "=" in x)
+    return int(kv.get("rounds", "1"))
 
 
 def l2_column_bytes(desc, N, d, m_pad, groups=1):
@@ -377,7 +384,7 @@ def main():
         f = fam.setdefault(kind, {"ms": 0.0, "bytes": 0.0, "launches": 0, "l2": 0.0, "l2_known": True})
         f["ms"] += rec["loop_ms"]
         f["bytes"] += ab * rec["n"]
-        f["launches"] += rec["n"]
+        f["launches"] += rec["n"] * plan_rounds(desc)
         if l2b is None:
             f["l2_known"] = False
         else:
@@ -386,7 +393,7 @@ def main():
         prep_ms_total += pm
         loop_ms_total += lm
         row = ("%-22s N=%4d d=%5d g=%4d m=%6d %-26s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg = %5.1f%% of 8 TB/s HBM%s)  prep %7.3f ms"
-               % (name, N, dg, groups, m, " ".join(desc.split()[:3]), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
+               % (name, N, dg, groups, m, " ".join(desc.split()[:3]) + (" x%d" % plan_rounds(desc) if plan_rounds(desc) > 1 else ""), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
                   "" if l2b is None else "; %5.0f GB/s L2 columns = %4.1f%% of 34.5 TB/s" % (l2b / lm / 1e6, l2b / lm / 1e6 / L2_PEAK_GBPS * 100),
                   pm))
         table.append(row)

@@ -336,6 +336,7 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.step = p.qc.step; sp.Kf = p.qc.Kf; sp.lamb = p.qc.lamb;
     sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
+    sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     return sp;
 }
@@ -393,7 +394,17 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
     e = hipMemsetAsync(scratch, 0, xbytes, st);
     if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, sp);
+    // Which workgroups share an XCD (blocks b and b+8 do under round-robin dispatch; speed only).  Members of one row
+    // tile together: every XCD's L2 pulls every column, 4-8 workgroups share a line.  Member c of every tile together
+    // (blockIdx = tile * C + c, C a multiple of 8): an L2 pulls 1/8 of each column for all tiles, but 32+ workgroups hit
+    // the same line at the same time.  Measured per column: layer1 (91 segments, two steps of look-ahead) 2.21 vs 2.36 us,
+    // 26 segments 1.90 vs 2.00 / 2.46 vs 2.56 -- tiles together; the variants with ONE step of look-ahead (their loads
+    // must land within a step) 3.47 vs 3.29 and 21.9 vs 20.6, and 197 segments in rounds (1.6 MB of columns per step
+    // and XCD) 139 vs 102 -- members together.
+    gpfq::SlabParams spx = sp;
+    const bool depth1 = (RT == 4 && maxw == 12) || (RT == 2 && maxw == 16);
+    spx.xcd_tiles = env_int("GPFQ_COOP_XCD_TILES", (!depth1 && pl.S <= 128) ? 1 : 0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ cooperative kernel launch");
     return GPFQ_OK;

@@ -92,6 +92,7 @@ struct SlabParams {
     int64_t ldw, ldq, ldu, ldi, m, m_pad;
     int Ng, d, S, C, tiles, idx_bytes, vec;
     int pace;          // cooperative kernels: pauses (s_sleep 1 each) between the column requests issued in the exchange window; 0 = off
+    int xcd_tiles;     // cooperative kernels: keep the members of a row tile on one XCD (needs tiles % 8 == 0)
     float step, Kf, lamb;
     unsigned spin_limit;
     uint64_t seed, row_id0;
@@ -299,7 +300,7 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
     int tile, c;
     // keep the members of one row tile on one XCD when the tile count allows it (blocks b and b+8 share an
     // XCD under round-robin dispatch; speed only, never correctness)
-    if ((p.tiles & 7) == 0) {
+    if (p.xcd_tiles && (p.tiles & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         tile = (j / C) * 8 + xcd;
         c = j % C;

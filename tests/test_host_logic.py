@@ -249,5 +249,9 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert bench.kernel_name("resident RT=2 waves=7 S=7 grid=(256,1) d=4608") == "gpfq_resident_rt2_m0_w8"
     assert bench.kernel_name("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == "gpfq_coop_rt4_m0_w12"
     assert bench.kernel_name("coop RT=2 C=4 waves=7 S=26 grid=256 d=1152", 1) == "gpfq_coop_rt2_m1_w8"
+    assert bench.kernel_name("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32 d=64") == "gpfq_coop_rt2_m0_w16"
+    assert bench.kernel_name("coop RT=4 C=32 waves=9 S=257 grid=256 rounds=2 d=147") == "gpfq_coop_rt4_m0_w12"
+    assert bench.plan_rounds("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32 d=64") == 32
+    assert bench.plan_rounds("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == 1
     assert bench.l2_column_bytes("resident RT=2 waves=7 S=7 grid=(256,1) d=4608", 512, 4608, 7168) == 256 * 4608 * 8 * 7168
     assert bench.l2_column_bytes("stream RT=4 waves=8 S=50 grid=(320,1) d=320", 1280, 320, 51200) is None

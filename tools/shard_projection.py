@@ -3,7 +3,9 @@
 rows one rank would own at world sizes 1, 2, 4 and 8 (full d, full columns -- every rank prepares all of them), and
 the per-rank step time is the sum over the layers plus a fixed allowance per layer for the int8 all_gather.
 
-    python tools/shard_projection.py > profiles/rNN_shard_projection.json           (on the GPU box)
+    python tools/shard_projection.py [workload] > profiles/rNN_shard_projection[_workload].json    (on the GPU box)
+
+workload: r50_3x3 (default, the headline) or any other key of tests/bench_workload.py WORKLOADS (r50_all, ...).
 
 This is a PROJECTION: no multi-GPU hardware run is behind it (the build pod has one GPU; the 1/2/4/8-GPU scaling run
 is the driver's).  What it measures is real -- the single-GPU kernels on the shard shapes -- what it assumes is that
@@ -45,7 +47,12 @@ def time_layer(W, A, X, m, step, reps=3):
 
 def main():
     dev = torch.device("cuda:0")
-    layers = [l[:4] for l in bw.resnet50_3x3_layers(1024)]
+    workload = sys.argv[1] if len(sys.argv) > 1 else "r50_3x3"
+    fn, batch, wdesc = bw.WORKLOADS[workload][:3]
+    layers = [l[:5] for l in bw.normalize_layers(fn(batch))]
+    if any(g != 1 for *_, g in layers):
+        sys.exit("grouped layers shard by groups, not by rows: not covered by this projection")
+    layers = [l[:4] for l in layers]
     shapes = {}
     for name, N, d, m in layers:
         shapes.setdefault((N, d, m), []).append(name)
@@ -76,7 +83,7 @@ def main():
     for k in worlds:
         proj[str(k)]["speedup_vs_1"] = round(proj["1"]["ms_per_step"] / proj[str(k)]["ms_per_step"], 3)
     out = {"what": "PROJECTION from single-GPU timings of the per-rank shard shapes; NO multi-GPU (N > 1) hardware run exists in this round",
-           "workload": "ResNet-50 sixteen 3x3 conv2 layers, calibration batch 1024 (bench.py default)",
+           "workload": "%s: %s" % (workload, wdesc),
            "assumptions": {"allgather_us_per_layer": ALLGATHER_US, "ranks_do_not_interfere": True,
                            "every_rank_prepares_all_columns": True},
            "kernel_source_sha256": _lib.kernel_source_digest(), "projected": proj, "per_shape": per_shape,
