@@ -63,6 +63,10 @@ _add_big("g6_128x1152x26624_msq_b4", 128, 1152, 26624)                     # Res
 _add_big("g6_512x1024x3072_msq_b4", 512, 1024, 3072)                       # layer4.1-2.conv2 rows, first 1024 of 4608 columns
 _add_big("g6_96x864x4096_soft_b2", 96, 864, 4096, bits=2, reg="L1", lamb=0.1)   # EfficientNet config (2-bit, L1)
 _add_big("g6_48x300x5000_hard_b3", 48, 300, 5000, bits=3, reg="L0", lamb=0.02)
+# long rows, more of them than the chip holds at once: the cooperative plan in rounds (ResNet-50's 1x1 convs at batch 1024)
+_add_big("g6_136x24x51200_msq_b4", 136, 24, 51200)                         # 50 segments, two rounds of 128 rows (16-wave two-row kernel)
+_add_big("g6_11x10x803840_msq_b4", 11, 10, 803840)                         # 785 segments, 64 members, 128 granules, two rounds of 8 rows
+_add_big("g6_40x12x201728_soft_b2", 40, 12, 201728, bits=2, reg="L1", lamb=0.1)   # 197 segments, 32 members x 4 rows, two rounds
 
 
 def make_inputs(case, seed_offset=0):

@@ -123,13 +123,18 @@ def check_big_case(name, got, where):
     assert np.array_equal(ck["U_head"][ok], fx["U_head"][ok])
     if not rep["rows_diverged"]:
         qe = float(np.sqrt(ck["U_sumsq"].sum()))
-        assert abs(qe - float(fx["quantize_error"])) <= 1e-4 * float(fx["quantize_error"])
+        # qe is the fp64 norm of a residual that equals the reference's bit for bit (checksums above); the fixture holds
+        # the reference's own fp32 torch.linalg.norm (step_algorithm.py:216), whose accumulation error grows with the
+        # element count (absorption: it comes out LOW): within 1e-4 up to 4 M elements, 2.1e-4 / 2.6e-4 / 3.7e-4 low on the 7.0 /
+        # 8.1 / 8.8 M elements of the three long-row fixtures -- there the bound is 1e-3
+        tol = 1e-4 if np.asarray(got["U"]).size <= (1 << 22) else 1e-3
+        assert abs(qe - float(fx["quantize_error"])) <= tol * float(fx["quantize_error"])
         if got.get("quantize_error") is not None:
-            assert abs(float(got["quantize_error"]) - float(fx["quantize_error"])) <= 1e-4 * float(fx["quantize_error"])
-            assert abs(float(got["relative_quantize_error"]) - float(fx["relative_quantize_error"])) <= 1e-4 * float(
+            assert abs(float(got["quantize_error"]) - float(fx["quantize_error"])) <= tol * float(fx["quantize_error"])
+            assert abs(float(got["relative_quantize_error"]) - float(fx["relative_quantize_error"])) <= tol * float(
                 fx["relative_quantize_error"])
         if got.get("relative_adder") is not None:
-            assert np.allclose(np.asarray(got["relative_adder"]), fx["relative_adder"], rtol=1e-4, atol=1e-6)
+            assert np.allclose(np.asarray(got["relative_adder"]), fx["relative_adder"], rtol=tol, atol=1e-6)
     print("%s %s: %d weights, %d/%d rows diverge at a tie (margins %s), fixture fp64 margin %.2e" % (
         where, name, rep["weights"], rep["rows_diverged"], rep["rows_compared"],
         ["%.1e" % t["margin"] for t in rep["ties"]], meta["margin"]))
