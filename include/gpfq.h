@@ -39,7 +39,8 @@ enum {
     GPFQ_PLAN_AUTO = 0,
     GPFQ_PLAN_STREAM = 1,     /* residual U streamed through HBM/L2 every step (any size)        */
     GPFQ_PLAN_RESIDENT = 2,   /* residual U resident in registers for the whole column loop      */
-    GPFQ_PLAN_COOP = 3,       /* resident, each row split by columns over C co-operating workgroups */
+    GPFQ_PLAN_COOP = 3,       /* resident, each row split by columns over C co-operating workgroups; more rows than
+                                 the chip holds at once run as one launch per block of rows on the caller's stream */
     GPFQ_PLAN_STREAM_ROWS = 4 /* streamed, whole rows per workgroup: never waits for another workgroup (the
                                  fallback after GPFQ_ERR_TIMEOUT; slower than the other plans on few long rows) */
 };

@@ -242,8 +242,10 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     got, src = bench.pmc_traffic("gpfq_resident_rt2_m0_w8", digest)
     assert got == 123 and src.endswith("r99_b_pmc_traffic.json")
     # and the committed summary of this round matches the committed sources, kernel names included
-    real = json.load(open(os.path.join(ROOT, "profiles", "r02_v2_pmc_traffic.json")))
-    assert real["source_sha256"] == digest, "profiles/r02_v2_pmc_traffic.json was collected on other kernel sources: re-collect"
+    import glob
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]
+    real = json.load(open(newest))
+    assert real["source_sha256"] == digest, "%s was collected on other kernel sources: re-collect (tools/profile_bench.sh)" % newest
     assert any("gpfq_resident_rt2_m0_w8" in k for k in real["kernels"]) and any("gpfq_coop_rt4_m0_w12" in k for k in real["kernels"])
     # the kernel names bench.py derives from a plan description are the names rocprofv3 reports
     assert bench.kernel_name("resident RT=2 waves=7 S=7 grid=(256,1) d=4608") == "gpfq_resident_rt2_m0_w8"
