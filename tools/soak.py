@@ -26,7 +26,7 @@ def main():
     t0 = time.time()
     bad = 0
     for ci in range(ncases):
-        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "stream", "grouped"])
+        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped"])
         groups = 1
         if fam == "wave":
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
@@ -39,12 +39,17 @@ def main():
             N, m = int(rng.integers(1, 24)), int(rng.integers(16385, 60000))
         elif fam == "coop_rows":                    # enough rows for the 2- and 4-row cooperative variants
             N, m = int(rng.integers(24, 300)), int(rng.integers(16385, 100000))
+        elif fam == "rounds":                       # long rows, a forced (rows, members) pair: more tiles than fit one launch
+            N, m = int(rng.integers(20, 200)), int(rng.integers(30000, 400000))
+            rt = int(rng.choice([1, 2, 4]))
+            os.environ["GPFQ_COOP_RT"] = str(rt)
+            os.environ["GPFQ_COOP_C"] = str(int(rng.choice([c for c in (8, 16, 32, 64, 128) if rt * c <= 128])))
         elif fam == "stream":
             N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
         else:
             groups = int(rng.choice([2, 3, 4]))
             N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
-        d = int(rng.integers(1, 12 if fam == "coop_rows" else 40))
+        d = int(rng.integers(1, 7 if fam == "rounds" else 12 if fam == "coop_rows" else 40))
         bits = int(rng.choice([2, 3, 4]))
         reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
         plan = 1 if fam == "stream" else 0
@@ -60,8 +65,11 @@ def main():
         _lib.check_status(dev)
         os.environ.pop("GPFQ_RESIDENT_RT", None)
         o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
-        desc = _lib.describe_plan(N, d, m, groups, plan).split()[0]
+        full = _lib.describe_plan(N, d, m, groups, plan)
+        desc = full.split()[0] + ("+rounds" if "rounds=" in full else "")
         kinds[desc] = kinds.get(desc, 0) + 1
+        os.environ.pop("GPFQ_COOP_RT", None)
+        os.environ.pop("GPFQ_COOP_C", None)
         ok = (np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
               and np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
               and np.array_equal(r["U"].cpu().numpy(), o["U"])
