@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define GPFQ_ABI_VERSION 2   /* 2: usq_seg outputs, GPFQ_PLAN_STREAM_ROWS, gpfq_last_launch_used_exchange */
+#define GPFQ_ABI_VERSION 3   /* 2: usq_seg outputs, GPFQ_PLAN_STREAM_ROWS, gpfq_last_launch_used_exchange
+                                3: nrm2 holds {norm, reciprocal} pairs: 2 * D floats */
 
 /* quantizer selection, step_algorithm.py:198-208 */
 enum {
@@ -91,11 +92,13 @@ int gpfq_last_launch_used_exchange(void);
 
 /*
  * Column preparation: AT[t][k] = A[k][t], XT[t][k] = X[k][t] for k < m, zero for m <= k < m_pad, and
- * nrm2[t] = ||X[:, t]||_2 ** 2 exactly as step_algorithm.py:142 spells it (sqrt of the sum of squares,
- * squared) with the canonical reduction order.  Replaces the strided column reads of
+ * nrm2[2t] = ||X[:, t]||_2 ** 2 exactly as step_algorithm.py:142 spells it (sqrt of the sum of squares,
+ * squared) with the canonical reduction order, nrm2[2t + 1] = 1 / nrm2[2t] (0 for a zero column; the loop kernels use
+ * it to find the alphabet index without a division on their critical path, and fall back to the reference's two
+ * divisions whenever the result could depend on them).  Replaces the strided column reads of
  * step_algorithm.py:141-148 (analog_layer_input[:, t], quantized_layer_input[:, t]).
  *   A, X   [m][lda / ldx]   D = number of columns used (groups * d_g)
- *   AT, XT [D][m_pad]       nrm2 [D]
+ *   AT, XT [D][m_pad]       nrm2 [2 * D]  (pairs; a group's slice starts at 2 * g * d_g)
  */
 int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
                              float* AT, float* XT, float* nrm2, int64_t m_pad, void* stream);
@@ -107,7 +110,7 @@ int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_
  * with the columns already prepared (gpfq_prepare_columns_f32).
  *   W   [N][ldw]  read only                 Q   [N][ldq]  written (alphabet values, fp32)
  *   U   [N][ldu]  residual: read as the initial value if u_has_init != 0 (else taken as 0), written at the end
- *   AT, XT [d][m_pad], nrm2 [d]             idx [N][ldi]  optional alphabet indices (may be NULL)
+ *   AT, XT [d][m_pad], nrm2 [2 * d]          idx [N][ldi]  optional alphabet indices (may be NULL)
  *   idx_bytes 1 (int8, needs K <= 126) or 2 (int16)
  *   index encoding: msq / soft / stochastic -> k in [-K, K], Q = sign(k)*step*|k|;
  *                   hard -> 0 or +-(k+1), k in [0, K], Q = +-(lamb + step*k)
@@ -144,8 +147,8 @@ int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const f
 
 /*
  * The second half of gpfq_quantize_layer_f32 on its own: all groups of a layer in one launch, on columns
- * already prepared by gpfq_prepare_columns_f32 with D = groups*d_g (AT, XT [groups*d_g][m_pad], nrm2
- * [groups*d_g]).  Lets a caller time / overlap the column preparation and the loop separately.
+ * already prepared by gpfq_prepare_columns_f32 with D = groups*d_g (AT, XT [groups*d_g][m_pad], nrm2 pairs
+ * [2*groups*d_g]).  Lets a caller time / overlap the column preparation and the loop separately.
  */
 int gpfq_quantize_groups_prepared_f32(const float* W, float* Q, float* U, const float* AT, const float* XT,
                                       const float* nrm2, int64_t N, int64_t d_g, int64_t m, int64_t m_pad,
@@ -162,8 +165,8 @@ int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, f
                        const float* uniform, float* out, int32_t* idx, void* stream);
 
 /*
- * nrm2[t] = ||column t||_2 ** 2 of columns that are already in the prepared layout XT [D][m_pad]
- * (step_algorithm.py:142), canonical reduction order -- the norm half of gpfq_prepare_columns_f32.
+ * nrm2[2t] = ||column t||_2 ** 2 and nrm2[2t + 1] = its reciprocal (nrm2 [2 * D]), of columns that are already in the
+ * prepared layout XT [D][m_pad] (step_algorithm.py:142), canonical reduction order -- the norm half of gpfq_prepare_columns_f32.
  */
 int gpfq_column_norms_f32(const float* XT, int64_t D, int64_t m, int64_t m_pad, float* nrm2, void* stream);
 

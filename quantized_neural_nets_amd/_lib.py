@@ -77,7 +77,7 @@ def _load():
     lib.gpfq_row_absmax_f32.argtypes = [vp, i64, i64, i64, vp, vp]
     lib.gpfq_describe_plan.restype = i32
     lib.gpfq_describe_plan.argtypes = [i64, i64, i64, i32, i32, c.c_char_p, sz]
-    if lib.gpfq_abi_version() != 2:
+    if lib.gpfq_abi_version() != 3:
         raise ImportError("libgpfq_hip.so ABI version mismatch")
     return lib
 

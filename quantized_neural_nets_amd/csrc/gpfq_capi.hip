@@ -334,6 +334,12 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.Ng = (int)p.Ng; sp.d = (int)p.d; sp.S = pl.S; sp.C = pl.C; sp.tiles = pl.tiles; sp.idx_bytes = p.idx_bytes;
     sp.vec = vec ? 1 : 0;
     sp.step = p.qc.step; sp.Kf = p.qc.Kf; sp.lamb = p.qc.lamb;
+    // the division-free MSQ path (gpfq_device.h quant_msq_from_dot) assumes a quotient that cannot underflow before the
+    // sign is taken and a tolerance that grows with K: steps outside 2^-40 .. 2^40 and K > 1024 (no real alphabet) keep
+    // the divisions (NaN fails every comparison)
+    const bool fast_ok = p.qc.step >= 0x1p-40f && p.qc.step <= 0x1p40f && p.qc.Kf <= 1024.0f && !env_int("GPFQ_EXACT_DIVISIONS", 0);
+    sp.inv_step = fast_ok ? 1.0f / p.qc.step : __builtin_nanf("");
+    sp.msq_thr = 0.5f - (p.qc.Kf + 4.0f) * 0x1p-18f;
     sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
     sp.xcd_tiles = 0;                               // launch_coop decides
@@ -581,7 +587,7 @@ static size_t ws_cols_bytes(int64_t d_g, int64_t m, int groups)
 }
 static size_t ws_nrm_bytes(int64_t d_g, int groups)
 {
-    return (((size_t)d_g * (size_t)groups * sizeof(float) + 255) / 256) * 256;
+    return ((2 * (size_t)d_g * (size_t)groups * sizeof(float) + 255) / 256) * 256;       // {norm, reciprocal} per column
 }
 
 size_t gpfq_workspace_bytes(int64_t N, int64_t d_g, int64_t m, int groups)

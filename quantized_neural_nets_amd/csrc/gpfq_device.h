@@ -65,6 +65,45 @@ __device__ __forceinline__ float wave_tree64_lane63(float v)
     return v;
 }
 
+// The lane trees of RT = 2 or 4 rows at once.  The four in-row levels run per row (afterwards every lane of a 16-lane
+// row holds that row's sum: A0..A3 for the first residual row, B0..B3 for the second, ...); the two cross-row levels
+// are SHARED: v_permlane16_swap(a, b) leaves a = [A0 B0 A2 B2], b = [A1 B1 A3 B3], so ONE add gives
+// [A0+A1, B0+B1, A2+A3, B2+B3] -- level five of both trees -- and v_permlane32_swap against a copy (two rows) or against
+// the other pair (four rows) sets up level six the same way.  Same additions, same tree, operands swapped at most
+// (fp add is commutative): bit-identical to wave_tree64_lane63 per row, in 13 instead of 20 (22 instead of 40)
+// instructions -- and a wave issues in order, so on the one-wave-per-SIMD kernels an instruction saved is ~5 cycles
+// off the step.  Result: the total of residual row r in every lane of lane row r (RT = 2: also in lane row r + 2).
+__device__ __forceinline__ float tree16_all(float v)
+{
+    v = v + dpp_mov<0xB1>(v);
+    v = v + dpp_mov<0x4E>(v);
+    v = v + dpp_mov<0x141>(v);
+    v = v + dpp_mov<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float swap16_add(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap32_add(float a, float b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+template <int RT>
+__device__ __forceinline__ float wave_tree64_rows(const float (&acc)[RT])
+{
+    static_assert(RT == 2 || RT == 4, "one row: wave_tree64_lane63");
+    const float s01 = swap16_add(tree16_all(acc[0]), tree16_all(acc[1]));
+    if constexpr (RT == 2) {
+        return swap32_add(s01, s01);
+    } else {
+        const float s23 = swap16_add(tree16_all(acc[2]), tree16_all(acc[3]));
+        return swap32_add(s01, s23);
+    }
+}
+
 // The same tree over the first nl lanes only (nl a power of two, wave-uniform): the upper levels, which
 // would add the +0.0f of idle lanes, are skipped (adding +0.0f is exact).  Result valid in lanes < nl.
 __device__ __forceinline__ float wave_tree_n(float v, int nl)
@@ -203,6 +242,41 @@ __device__ __forceinline__ float quant_msq(float step, float x, float Kf, int& i
     float sg = sgnf(x);
     idx = (int)(sg * r);
     return (sg * step) * r;
+}
+
+// The same quantizer from the DOT PRODUCT v = <u, x_t>, without the two divisions whenever the answer cannot depend on
+// them -- in TWELVE vector instructions instead of about fifty.  (A resident workgroup runs one wave per SIMD, and a wave
+// issues in order: every instruction of the step is on its critical path, whatever the data dependences say.)
+// step_algorithm.py:145-146 computes  z = fl(fl(v / n2) / step)  and rounds  floor(fl(z + 0.5));  c is the per-column
+// constant fl(fl(1 / n2) * fl(1 / step)), so  r = fl(v * c)  is within 5 roundings of the real quotient and z within 2:
+// |fl(z + 0.5) - fl(r + 0.5)| < 0.7 * 2^-20 * |r| + 2^-24.  With  f = y - floor(y)  (exact), y = fl(r + 0.5):
+//   * |r| <= K + 4:  if f keeps more than (K + 4) * 2^-18 from 0 and from 1 -- |f - 0.5| < thr = 0.5 - (K + 4) * 2^-18,
+//     one compare -- the reference's floor is floor(y);
+//   * |r| >  K + 4:  both floors are beyond K and the clip min(|floor|, K) returns K for both, whatever f is.
+// Everything behind the floor is the reference's own arithmetic: magnitude step * min(|floor|, K) ((+-1 * step) * rm has
+// the same magnitude), sign of s = fl(v / n2) = sign of v as long as the quotient cannot underflow to zero (|r| >= 2^-60
+// and step >= 2^-40, checked by the host), index (int)(+-rm).  v == 0, NaN, Inf, |r| >= 2^23 fail one of the two compares.
+// Otherwise the caller runs the divisions: the function returns false and q / idx are not to be used (about one value
+// in 10^4 at 4 bits).  The host switches the path off (c = NaN) for K > 1024.
+// Checked against the division form on 4.8 * 10^9 random and boundary-hugging arguments, 0 mismatches, and the check
+// does find mismatches with a tolerance of 2^-23 (tests/csrc/msq_fast_check.c; tests/test_host_logic.py runs a short pass).
+// Returns whether every lane whose answer is USED may keep it (wave-uniform; Kf, step, thr are uniform values; `unused`
+// is the mask of the lanes nobody reads -- they hold zeros, and a zero dot product never passes).
+__device__ __forceinline__ bool quant_msq_from_dot(float v, float c, float step, float Kf, float thr,
+                                                   unsigned long long unused, float& q, int& idx)
+{
+    const float r = v * c;
+    const float y = r + 0.5f;
+    const float fl = floorf(y);
+    const float d = (y - fl) - 0.5f;
+    float rm;
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(rm) : "v"(fl), "s"(Kf));       // (fminf would canonicalize both operands first)
+    q = __builtin_copysignf(step * rm, v);
+    idx = (int)__builtin_copysignf(rm, v);
+    // the two compare masks straight into the scalar unit (a bool per lane would be materialised and compared again)
+    const unsigned long long ok = __builtin_amdgcn_ballot_w64(__builtin_fabsf(d) < thr) &
+                                  __builtin_amdgcn_ballot_w64(__builtin_fabsf(r) >= 0x1p-60f);
+    return (ok | unused) == __builtin_amdgcn_read_exec();
 }
 
 // step_algorithm.py:103-104

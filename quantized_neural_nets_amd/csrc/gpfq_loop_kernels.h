@@ -14,7 +14,8 @@ struct LoopParams {
     const float* W; int64_t ldw;
     float* Q; int64_t ldq;
     float* U; int64_t ldu; int u_has_init;
-    const float* AT; const float* XT; const float* nrm2;
+    const float* AT; const float* XT;
+    const float* nrm2; // [columns][2]: ||x_t||^2 and its reciprocal (0 for a zero column)
     int64_t Ng;        // rows per group
     int64_t d;         // columns per group
     int64_t m; int64_t m_pad; int S;
@@ -94,6 +95,8 @@ struct SlabParams {
     int pace;          // cooperative kernels: pauses (s_sleep 1 each) between the column requests issued in the exchange window; 0 = off
     int xcd_tiles;     // cooperative kernels: keep the members of a row tile on one XCD (needs tiles % 8 == 0)
     float step, Kf, lamb;
+    float inv_step;    // fl(1 / step) for quant_msq_from_dot; NaN switches the division-free path off
+    float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
     unsigned spin_limit;
     uint64_t seed, row_id0;
 };
@@ -115,10 +118,10 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 // members (max(16, C/2) when RT * C > 64) -- so that both trees run all their levels without testing how many are needed: a taken branch costs
 // ~20 cycles on this chain, and adding +0.0f is exact (a partial sum is never -0.0f, see wave_tree16_zero_padded).
 // Returns whether the exchange timed out (wave-uniform; the same fact is left in the abort word of qs for the other waves).
-template <int RT, int MODE>
+template <int RT, int MODE, bool FAST>
 __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int lane, int tile, int c, int C, int par,
-                                        int t, float n2cur, int row0, int64_t grow0, int seg_lo)
+                                        int t, float n2cur, float ccur, int row0, int64_t grow0, int seg_lo)
 {
     // this workgroup's block of the slot tree for all RT rows at once: lane = 16 * row + slot
     float v;
@@ -175,19 +178,36 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         if (sh > 5) v = xor32_add(v);
     }
     const bool lead = member == 0 && gr_ < RT;
-    const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
     const bool rvalid = lead && (row0 + gr_ < p.Ng);
     const int64_t growl = grow0 + (rvalid ? gr_ : 0);
     int id;
-    const float q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
-    if (lead) qs[par * (RT + 1) + gr_] = q;
+    float q;
+    // MSQ: index and value straight from the dot product (gpfq_device.h quant_msq_from_dot), the divisions only on the
+    // rare step whose quotient lies within 2^-19 of a rounding boundary in some lane; used first, checked second (see
+    // resident_body).  FAST is off in the four-row 12-wave variant: both paths do not fit the 56 registers it leaves
+    // the compiler.
+    bool redo = false;
+    auto divide_and_quantize = [&]() {
+        const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+        q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
+    };
+    if (FAST) redo = !quant_msq_from_dot(v, ccur, p.step, p.Kf, p.msq_thr, ~__builtin_amdgcn_ballot_w64(lead), q, id);
+    else divide_and_quantize();
     // Q / idx leave through a 64-step history in LDS and one coalesced store per row every 64 steps: a
     // store per step would queue behind the sweep waves' column loads in the vector-memory pipe and hold up
     // the reducer's arrival at the second barrier.
     float* hist = qs + 2 * (RT + 1);                 // [RT][64] values, then [RT][64] indices (as int bits)
-    if (lead) {
-        hist[gr_ * 64 + (t & 63)] = q;
-        hist[(RT + gr_) * 64 + (t & 63)] = __int_as_float(id);
+    auto commit = [&]() {
+        if (lead) {
+            qs[par * (RT + 1) + gr_] = q;
+            hist[gr_ * 64 + (t & 63)] = q;
+            hist[(RT + gr_) * 64 + (t & 63)] = __int_as_float(id);
+        }
+    };
+    commit();
+    if (FAST && __builtin_expect(redo, 0)) {
+        divide_and_quantize();
+        commit();
     }
     if (__builtin_expect((t & 63) == 63 || t + 1 == p.d, 0)) {
         const int t0 = t & ~63;
@@ -339,6 +359,7 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         wcur[r] = wrow[r][0];
     }
     float n2cur = nrm[0];
+    float ccur = nrm[1] * p.inv_step;               // fl(1 / ||x_t||^2) * fl(1 / step): the constant of quant_msq_from_dot
 
     // the residual starts at 0 (a non-zero initial residual is the streaming plan's job); every buffer starts defined
     win_zero16<U0>();
@@ -415,10 +436,12 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
                 acc[3] = win_sweep16<U0 + 48, XP, AC, XC>(qprev[3], wcur[3]);
             }
             GPFQ_STAMP(1)
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                const float sg = wave_tree64_lane63(acc[r]);
-                if (lane == 63) seg[r * NW + wave] = sg;
+            if constexpr (RT == 1) {
+                const float sg = wave_tree64_lane63(acc[0]);
+                if (lane == 63) seg[wave] = sg;
+            } else {                                // row r's total in lane row r: one LDS write for all rows
+                const float tot = wave_tree64_rows<RT>(acc);
+                if ((lane & 15) == 0 && (lane >> 4) < RT) seg[(lane >> 4) * NW + wave] = tot;
             }
             // The next column wanted goes into the registers the sweeps have just finished with (x_{t-1}'s and a_t's).
             // A wave that is also the reducer requests three quarters here and the last one behind barrier 2, as in
@@ -443,10 +466,10 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         const int tn = more ? t + 1 : t;
 #pragma unroll
         for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
-        const float n2n = nrm[tn];
+        const float n2n = nrm[2 * tn], in2n = nrm[2 * tn + 1];
         if (wave == rwave) {
             GPFQ_STAMP(4)
-            reducer_section<RT, MODE>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, row0, grow0, seg_lo);
+            reducer_section<RT, MODE, (MODE == MODE_MSQ && !(RT == 4 && DEPTH == 1))>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, ccur, row0, grow0, seg_lo);
             GPFQ_STAMP(5)
         } else if (trickle && active) {
             // The exchange window: the sweep waves idle here for ~2 000 cycles while the reducer's granules travel.  Their
@@ -479,6 +502,7 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
+        ccur = in2n * p.inv_step;
         ++t;
         return true;
     };
@@ -584,7 +608,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
     const float* xload = uniform_ptr(p.XT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const float* aload = uniform_ptr(p.AT + (int64_t)g * p.d * p.m_pad + (int64_t)wave * kSeg);
     const unsigned lane_off = 16u * (unsigned)lane;
-    const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
+    const kfloat* nrm = as_scalar(p.nrm2 + 2 * (int64_t)g * p.d);
     // "this is wave 0" as a scalar, so that the flush test of the Q / idx history is a scalar branch
     const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
 
@@ -602,6 +626,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         ihist[r] = 0;
     }
     float n2cur = nrm[0];
+    float ccur = nrm[1] * p.inv_step;               // fl(1 / ||x_t||^2) * fl(1 / step): the constant of quant_msq_from_dot
 
     // the residual starts at 0 (a non-zero initial residual is the streaming plan's job); x_t lives in X[t % 3],
     // a_t in A[t % 2]; X2 starts as x_{-1} = 0 (q_{-1} = 0)
@@ -637,6 +662,8 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
 #define GPFQ_RSTAMP(i)
 #endif
     int t = 0;
+    // the lanes q is read from (v_readlane 16 * r): the only ones whose quantizer result is used
+    constexpr unsigned long long kRowLanes = RT == 1 ? 0x1ull : (RT == 2 ? 0x10001ull : 0x1000100010001ull);
     // one step; XP holds x_{t-1}, XC x_t, AC a_t.  Returns false after the last column.
     auto step = [&](auto xp_, auto xc_, auto ac_) -> bool {
         constexpr int XP = decltype(xp_)::value, XC = decltype(xc_)::value, AC = decltype(ac_)::value;
@@ -662,10 +689,12 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         }
         win_load4<XP, 0>(xload, lane_off);
         win_load4<AC, 0>(aload, lane_off);
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const float sg = wave_tree64_lane63(acc[r]);
-            if (lane == 63) seg[r * S + wave] = sg;
+        if constexpr (RT == 1) {
+            const float sg = wave_tree64_lane63(acc[0]);
+            if (lane == 63) seg[wave] = sg;
+        } else {                                    // row r's total in lane row r: one LDS write for all rows
+            const float tot = wave_tree64_rows<RT>(acc);
+            if ((lane & 15) == 0 && r16 < RT) seg[r16 * S + wave] = tot;
         }
         float uni = 0.0f;
         if (MODE == MODE_STOCHASTIC)
@@ -694,24 +723,39 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         float wn[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
-        const float n2n = nrm[tn];
-        __builtin_amdgcn_sched_barrier(0);          // ... and keeps them from sinking below the divisions
-        const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+        const float n2n = nrm[2 * tn], in2n = nrm[2 * tn + 1];
+        __builtin_amdgcn_sched_barrier(0);          // ... and keeps them from sinking below the quantizer
         int id;
         float q;
-        if (MODE == MODE_SOFT) q = quant_soft(p.step, sarg, p.Kf, p.lamb, id);
-        else if (MODE == MODE_HARD) q = quant_hard(p.step, sarg, p.Kf, p.lamb, id);
-        else if (MODE == MODE_STOCHASTIC) q = quant_stochastic(p.step, sarg, p.Kf, uni, id);
-        else q = quant_msq(p.step, sarg, p.Kf, id);
+        // MSQ: index and value straight from the dot product (gpfq_device.h quant_msq_from_dot), and the reference's two
+        // divisions only on the rare step whose quotient lies within 2^-19 of a rounding boundary.  The answer is used
+        // first and checked second: the check is a chain of its own, as long as the one to q, and a branch in front of
+        // the readlanes would put it back on the critical path; behind them its condition has long been computed.  (The
+        // same bits in every wave, so every wave takes the same side.)
+        bool redo = false;
+        auto divide_and_quantize = [&]() {
+            const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+            if (MODE == MODE_SOFT) q = quant_soft(p.step, sarg, p.Kf, p.lamb, id);
+            else if (MODE == MODE_HARD) q = quant_hard(p.step, sarg, p.Kf, p.lamb, id);
+            else if (MODE == MODE_STOCHASTIC) q = quant_stochastic(p.step, sarg, p.Kf, uni, id);
+            else q = quant_msq(p.step, sarg, p.Kf, id);
+        };
+        if (MODE == MODE_MSQ) redo = !quant_msq_from_dot(v, ccur, p.step, p.Kf, p.msq_thr, ~kRowLanes, q, id);
+        else divide_and_quantize();
         // Q / idx: 64 steps of history in registers (lane l holds step t0 + l), one coalesced store every 64 steps
+        auto commit = [&]() {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), 16 * r));
-#ifdef GPFQ_STAMPS
-            if (r == RT - 1) GPFQ_RSTAMP(5)
-#endif
-            const int idr = __builtin_amdgcn_readlane(id, 16 * r);
-            if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+            for (int r = 0; r < RT; ++r) {
+                qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), 16 * r));
+                const int idr = __builtin_amdgcn_readlane(id, 16 * r);
+                if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+            }
+        };
+        commit();
+        GPFQ_RSTAMP(5)
+        if (MODE == MODE_MSQ && __builtin_expect(redo, 0)) {
+            divide_and_quantize();
+            commit();
         }
         if (__builtin_expect(((t & 63) == 63 || !more) && wave0, 0)) {
             const int t0 = t & ~63;
@@ -735,6 +779,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
+        ccur = in2n * p.inv_step;
         ++t;
         return true;
     };
@@ -816,7 +861,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
     const int64_t kbase = 4 * lane;
     const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
     const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
-    const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
+    const kfloat* nrm = as_scalar(p.nrm2 + 2 * (int64_t)g * p.d);
 
     float u[RT][16], X0[16], X1[16], A0[16];
     const kfloat* wrow[RT];
@@ -835,6 +880,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
     load16(X0, xcol);
     load16(A0, acol);
     float n2cur = nrm[0];
+    float ccur = nrm[1] * p.inv_step;               // fl(1 / ||x_t||^2) * fl(1 / step): the constant of quant_msq_from_dot
     float qhist[RT];                                // Q / idx history: lane l holds step t0 + l, one register per row
     int ihist[RT];
 #pragma unroll
@@ -860,7 +906,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
         float wn[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
-        const float n2n = nrm[tn];
+        const float n2n = nrm[2 * tn], in2n = nrm[2 * tn + 1];
         // the RT row totals, row r parked in lane r, then ONE quantizer evaluation for all rows
         float v = 0.0f;
 #pragma unroll
@@ -869,14 +915,27 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
             const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg), 63));
             if (lane == r) v = tot;
         }
-        const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
         int id;
-        const float q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)(grow0 + (lane < RT ? lane : 0)), (uint64_t)t, id);
+        float q;
+        bool redo = false;                          // use first, check second: see resident_body
+        auto divide_and_quantize = [&]() {
+            const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
+            q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)(grow0 + (lane < RT ? lane : 0)), (uint64_t)t, id);
+        };
+        if (MODE == MODE_MSQ) redo = !quant_msq_from_dot(v, ccur, p.step, p.Kf, p.msq_thr, ~((1ull << RT) - 1ull), q, id);
+        else divide_and_quantize();
+        auto commit = [&]() {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), r));
-            const int idr = __builtin_amdgcn_readlane(id, r);
-            if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+            for (int r = 0; r < RT; ++r) {
+                qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), r));
+                const int idr = __builtin_amdgcn_readlane(id, r);
+                if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
+            }
+        };
+        commit();
+        if (MODE == MODE_MSQ && __builtin_expect(redo, 0)) {
+            divide_and_quantize();
+            commit();
         }
         if (__builtin_expect((t & 63) == 63 || !more, 0)) {
             const int t0 = t & ~63;
@@ -898,6 +957,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
+        ccur = in2n * p.inv_step;
         ++t;
         return true;
     };
@@ -973,7 +1033,7 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCo
     const int64_t row0 = (int64_t)tile * RT;
     const float* __restrict__ ATg = p.AT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
     const float* __restrict__ XTg = p.XT + ((int64_t)g * p.d) * p.m_pad + 4 * lane;
-    const kfloat* nrm = as_scalar(p.nrm2 + (int64_t)g * p.d);
+    const kfloat* nrm = as_scalar(p.nrm2 + 2 * (int64_t)g * p.d);
     const kfloat* Wk = as_scalar(p.W);
 
     int64_t grow[RT];
@@ -1066,7 +1126,7 @@ __global__ void __launch_bounds__(512) gpfq_stream_kernel(LoopParams p, StreamCo
             }
             const int gr_ = lane / blk;
             const bool lead = (lane % blk == 0) && gr_ < RT;
-            const float n2 = nrm[t];
+            const float n2 = nrm[2 * t];
             const float sv = (n2 > 0.0f) ? v / n2 : 0.0f;
             const bool rvalid = lead && (row0 + gr_ < p.Ng);
             const int64_t growl = (int64_t)g * p.Ng + (rvalid ? row0 + gr_ : p.Ng - 1);

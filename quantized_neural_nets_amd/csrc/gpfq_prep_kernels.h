@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(256) gpfq_transpose_pad_kernel(const float* __
     }
 }
 
-// nrm2[t] = (sqrt(cdot(x_t, x_t)))^2, canonical order.  One 256-thread workgroup per column; dynamic LDS S floats.
+// nrm2[2t] = (sqrt(cdot(x_t, x_t)))^2, canonical order, nrm2[2t + 1] = its reciprocal (0 for a zero column).
+// One 256-thread workgroup per column; dynamic LDS S floats.
 __global__ void __launch_bounds__(256) gpfq_colnorm_kernel(const float* __restrict__ XT, int64_t m_pad, int S,
                                                            float* __restrict__ nrm2)
 {
@@ -67,7 +68,11 @@ __global__ void __launch_bounds__(256) gpfq_colnorm_kernel(const float* __restri
         const SlotMap smap = make_slot_map(S, P, 0, per, lane, nl);
         float tot = combine_slots<true>(seg, smap, per, nl, S - 1);
         float r = sqrtf(tot);
-        if (lane == 0) nrm2[col] = r * r;
+        if (lane == 0) {
+            const float n2 = r * r;
+            nrm2[2 * col] = n2;
+            nrm2[2 * col + 1] = (n2 > 0.0f) ? 1.0f / n2 : 0.0f;      // for quant_msq_from_dot (gpfq_device.h)
+        }
     }
 }
 

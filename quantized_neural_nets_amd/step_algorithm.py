@@ -157,7 +157,7 @@ class StepAlgorithm:
         mp = _lib.lib.gpfq_padded_m(m)
         AT = torch.empty((max(d, 1), mp), device=dev, dtype=torch.float32)
         XT = torch.empty((max(d, 1), mp), device=dev, dtype=torch.float32)
-        nrm2 = torch.empty((max(d, 1),), device=dev, dtype=torch.float32)
+        nrm2 = torch.empty((2 * max(d, 1),), device=dev, dtype=torch.float32)      # {norm, reciprocal} per column (ABI 3)
         st = _lib.current_stream_ptr(dev)
         scr = _lib.scratch(dev)
         _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A), lda, _ptr(X), ldx, m, d, _ptr(AT), _ptr(XT),
@@ -279,7 +279,7 @@ class StepAlgorithm:
             # the two halves of gpfq_quantize_layer_f32, called separately so that a profiler hook can
             # bracket the column preparation and the loop kernel with events on the current stream
             D = groups_loc * dg
-            nrm2 = torch.empty((D,), device=dev, dtype=torch.float32)
+            nrm2 = torch.empty((2 * D,), device=dev, dtype=torch.float32)          # {norm, reciprocal} per column (ABI 3)
             hook = event_hook
             if hook:
                 hook("prepare_begin", (Nl, dg, mm, groups_loc))

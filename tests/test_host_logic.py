@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared:
         assert hasattr(raw, name), "libgpfq_hip.so does not export " + name
     assert declared == set(lib.EXPORTS), (declared ^ set(lib.EXPORTS))
-    assert lib.lib.gpfq_abi_version() == 2
+    assert lib.lib.gpfq_abi_version() == 3
 
 
 def test_padding_and_workspace(lib):
@@ -257,3 +257,27 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert bench.plan_rounds("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == 1
     assert bench.l2_column_bytes("resident RT=2 waves=7 S=7 grid=(256,1) d=4608", 512, 4608, 7168) == 256 * 4608 * 8 * 7168
     assert bench.l2_column_bytes("stream RT=4 waves=8 S=50 grid=(320,1) d=320", 1280, 320, 51200) is None
+
+
+def test_division_free_msq_form_equals_the_division_form(tmp_path):
+    """The loop kernels find the MSQ index from ONE multiplication of the dot product (gpfq_device.h quant_msq_from_dot)
+    and run the reference's two divisions only when the product lies within (K + 4) * 2^-18 of a rounding boundary.  The
+    C restatement of both forms (tests/csrc/msq_fast_check.c, every operation individually rounded) compares them on
+    random and boundary-hugging arguments: wherever the fast form claims an answer it must be the division form's, bit
+    for bit.  (4.8e9 samples were run once; this pass is 1.6e7.)  The check itself is checked: with the tolerance at
+    (K + 4) * 2^-24 it must find mismatches."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "csrc", "msq_fast_check.c")
+    exe = str(tmp_path / "msq_fast_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe, "2000000", "11"], check=True, capture_output=True, text=True).stdout
+    assert " 0 mismatches" in out, out
+    frac = float(out.split(" samples, ")[1].split()[0])
+    assert 0.2 < frac < 0.9, out                     # both sides of the guard are exercised
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-DTOL_UNIT=0x1p-24f", "-o", exe + "_loose", src, "-lm"], check=True)
+    loose = subprocess.run([exe + "_loose", "2000000", "11"], capture_output=True, text=True)
+    assert loose.returncode == 1 and " 0 mismatches" not in loose.stdout, loose.stdout
+    # the device helper uses the constants the check was run with
+    dev = open(os.path.join(ROOT, "quantized_neural_nets_amd", "csrc", "gpfq_device.h")).read()
+    host = open(os.path.join(ROOT, "quantized_neural_nets_amd", "csrc", "gpfq_capi.hip")).read()
+    assert "(p.qc.Kf + 4.0f) * 0x1p-18f" in host and "0x1p-60f" in dev and "p.qc.Kf <= 1024.0f" in host
