@@ -247,9 +247,9 @@ __device__ __forceinline__ float quant_msq(float step, float x, float Kf, int& i
 // The same quantizer from the DOT PRODUCT v = <u, x_t>, without the two divisions whenever the answer cannot depend on
 // them -- in TWELVE vector instructions instead of about fifty.  (A resident workgroup runs one wave per SIMD, and a wave
 // issues in order: every instruction of the step is on its critical path, whatever the data dependences say.)
-// step_algorithm.py:145-146 computes  z = fl(fl(v / n2) / step)  and rounds  floor(fl(z + 0.5));  c is the per-column
-// constant fl(fl(1 / n2) * fl(1 / step)), so  r = fl(v * c)  is within 5 roundings of the real quotient and z within 2:
-// |fl(z + 0.5) - fl(r + 0.5)| < 0.7 * 2^-20 * |r| + 2^-24.  With  f = y - floor(y)  (exact), y = fl(r + 0.5):
+// step_algorithm.py:145-146 computes  z = fl(fl(v / n2) / step)  and rounds  floor(fl(z + 0.5));  with the per-column
+// in2 = fl(1 / n2) (column preparation) and inv_step = fl(1 / step) (host),  r = fl(fl(v * in2) * inv_step)  is within 4
+// roundings of the real quotient and z within 2:  |fl(z + 0.5) - fl(r + 0.5)| < 0.7 * 2^-20 * |r| + 2^-24.  With  f = y - floor(y)  (exact), y = fl(r + 0.5):
 //   * |r| <= K + 4:  if f keeps more than (K + 4) * 2^-18 from 0 and from 1 -- |f - 0.5| < thr = 0.5 - (K + 4) * 2^-18,
 //     one compare -- the reference's floor is floor(y);
 //   * |r| >  K + 4:  both floors are beyond K and the clip min(|floor|, K) returns K for both, whatever f is.
@@ -257,15 +257,16 @@ __device__ __forceinline__ float quant_msq(float step, float x, float Kf, int& i
 // the same magnitude), sign of s = fl(v / n2) = sign of v as long as the quotient cannot underflow to zero (|r| >= 2^-60
 // and step >= 2^-40, checked by the host), index (int)(+-rm).  v == 0, NaN, Inf, |r| >= 2^23 fail one of the two compares.
 // Otherwise the caller runs the divisions: the function returns false and q / idx are not to be used (about one value
-// in 10^4 at 4 bits).  The host switches the path off (c = NaN) for K > 1024.
+// in 10^4 at 4 bits).  The host switches the path off (inv_step = NaN) for K > 1024.
+// n2 == 0: in2 == 0 and v == +0 (a zero column): the divisions run (and return 0, as the reference's guard does).
 // Checked against the division form on 4.8 * 10^9 random and boundary-hugging arguments, 0 mismatches, and the check
 // does find mismatches with a tolerance of 2^-23 (tests/csrc/msq_fast_check.c; tests/test_host_logic.py runs a short pass).
 // Returns whether every lane whose answer is USED may keep it (wave-uniform; Kf, step, thr are uniform values; `unused`
 // is the mask of the lanes nobody reads -- they hold zeros, and a zero dot product never passes).
-__device__ __forceinline__ bool quant_msq_from_dot(float v, float c, float step, float Kf, float thr,
+__device__ __forceinline__ bool quant_msq_from_dot(float v, float in2, float inv_step, float step, float Kf, float thr,
                                                    unsigned long long unused, float& q, int& idx)
 {
-    const float r = v * c;
+    const float r = (v * in2) * inv_step;
     const float y = r + 0.5f;
     const float fl = floorf(y);
     const float d = (y - fl) - 0.5f;
@@ -383,9 +384,16 @@ __device__ __forceinline__ float sweep16(float (&u)[16], const float (&xp)[16], 
 // proven), and a dword load at the tail of the in-order vector-memory counter makes its consumer wait for every
 // column load issued before it.
 typedef const float __attribute__((address_space(4))) kfloat;
+typedef const char __attribute__((address_space(4))) kchar;
 __device__ __forceinline__ const kfloat* as_scalar(const float* p)
 {
     return reinterpret_cast<const kfloat*>(reinterpret_cast<uintptr_t>(p));
+}
+// scalar load at a 32-bit BYTE offset from a uniform base: s_load_dword sdst, sbase, soffset -- no 64-bit address
+// arithmetic (a[i] with a signed int costs six scalar instructions per address, and a wave issues them in order)
+__device__ __forceinline__ float sload(const kfloat* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const kfloat*>(reinterpret_cast<const kchar*>(base) + byte_off);
 }
 
 __device__ __forceinline__ void load16(float (&dst)[16], const float* __restrict__ p /* + 4*lane applied */)

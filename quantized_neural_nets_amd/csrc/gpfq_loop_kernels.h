@@ -121,7 +121,7 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 template <int RT, int MODE, bool FAST>
 __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int lane, int tile, int c, int C, int par,
-                                        int t, float n2cur, float ccur, int row0, int64_t grow0, int seg_lo)
+                                        int t, float n2cur, float in2cur, int row0, int64_t grow0, int seg_lo)
 {
     // this workgroup's block of the slot tree for all RT rows at once: lane = 16 * row + slot
     float v;
@@ -191,7 +191,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
         q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)t, id);
     };
-    if (FAST) redo = !quant_msq_from_dot(v, ccur, p.step, p.Kf, p.msq_thr, ~__builtin_amdgcn_ballot_w64(lead), q, id);
+    if (FAST) redo = !quant_msq_from_dot(v, in2cur, p.inv_step, p.step, p.Kf, p.msq_thr, ~__builtin_amdgcn_ballot_w64(lead), q, id);
     else divide_and_quantize();
     // Q / idx leave through a 64-step history in LDS and one coalesced store per row every 64 steps: a
     // store per step would queue behind the sweep waves' column loads in the vector-memory pipe and hold up
@@ -359,7 +359,7 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         wcur[r] = wrow[r][0];
     }
     float n2cur = nrm[0];
-    float ccur = nrm[1] * p.inv_step;               // fl(1 / ||x_t||^2) * fl(1 / step): the constant of quant_msq_from_dot
+    float in2cur = nrm[1];                          // fl(1 / ||x_t||^2) for quant_msq_from_dot
 
     // the residual starts at 0 (a non-zero initial residual is the streaming plan's job); every buffer starts defined
     win_zero16<U0>();
@@ -465,11 +465,11 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         float wn[RT];
         const int tn = more ? t + 1 : t;
 #pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
-        const float n2n = nrm[2 * tn], in2n = nrm[2 * tn + 1];
+        for (int r = 0; r < RT; ++r) wn[r] = sload(wrow[r], 4u * (unsigned)tn);
+        const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
         if (wave == rwave) {
             GPFQ_STAMP(4)
-            reducer_section<RT, MODE, (MODE == MODE_MSQ && !(RT == 4 && DEPTH == 1))>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, ccur, row0, grow0, seg_lo);
+            reducer_section<RT, MODE, (MODE == MODE_MSQ && !(RT == 4 && DEPTH == 1))>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, in2cur, row0, grow0, seg_lo);
             GPFQ_STAMP(5)
         } else if (trickle && active) {
             // The exchange window: the sweep waves idle here for ~2 000 cycles while the reducer's granules travel.  Their
@@ -502,7 +502,7 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
-        ccur = in2n * p.inv_step;
+        in2cur = in2n;
         ++t;
         return true;
     };
@@ -626,7 +626,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         ihist[r] = 0;
     }
     float n2cur = nrm[0];
-    float ccur = nrm[1] * p.inv_step;               // fl(1 / ||x_t||^2) * fl(1 / step): the constant of quant_msq_from_dot
+    float in2cur = nrm[1];                          // fl(1 / ||x_t||^2) for quant_msq_from_dot
 
     // the residual starts at 0 (a non-zero initial residual is the streaming plan's job); x_t lives in X[t % 3],
     // a_t in A[t % 2]; X2 starts as x_{-1} = 0 (q_{-1} = 0)
@@ -662,6 +662,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
 #define GPFQ_RSTAMP(i)
 #endif
     int t = 0;
+    const int dlast = p.d - 1;
     // the lanes q is read from (v_readlane 16 * r): the only ones whose quantizer result is used
     constexpr unsigned long long kRowLanes = RT == 1 ? 0x1ull : (RT == 2 ? 0x10001ull : 0x1000100010001ull);
     // one step; XP holds x_{t-1}, XC x_t, AC a_t.  Returns false after the last column.
@@ -716,14 +717,15 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         // step they made the `s_waitcnt lgkmcnt(0)` in front of the sweep wait a whole scalar-cache round trip.  From
         // here the next wait on the counter is a full quantizer away.  The scheduling barrier keeps the tree above, the
         // opaque asm (its result is the address) keeps the requests below.
-        int tn = more ? t + 1 : t;
+        // byte offset of the next column's weight (the last step re-reads its own); min, not a select on `more`: a
+        // select on a lane-mask boolean is vector code
+        unsigned tn4 = 4u * (unsigned)(t + 1 < dlast ? t + 1 : dlast);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(tn)::"memory");
-        tn = __builtin_amdgcn_readfirstlane(tn);    // (an asm result counts as divergent; this makes it scalar again)
+        asm volatile("" : "+s"(tn4)::"memory");
         float wn[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
-        const float n2n = nrm[2 * tn], in2n = nrm[2 * tn + 1];
+        for (int r = 0; r < RT; ++r) wn[r] = sload(wrow[r], tn4);
+        const float n2n = sload(nrm, 2u * tn4), in2n = sload(nrm, 2u * tn4 + 4u);
         __builtin_amdgcn_sched_barrier(0);          // ... and keeps them from sinking below the quantizer
         int id;
         float q;
@@ -740,7 +742,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
             else if (MODE == MODE_STOCHASTIC) q = quant_stochastic(p.step, sarg, p.Kf, uni, id);
             else q = quant_msq(p.step, sarg, p.Kf, id);
         };
-        if (MODE == MODE_MSQ) redo = !quant_msq_from_dot(v, ccur, p.step, p.Kf, p.msq_thr, ~kRowLanes, q, id);
+        if (MODE == MODE_MSQ) redo = !quant_msq_from_dot(v, in2cur, p.inv_step, p.step, p.Kf, p.msq_thr, ~kRowLanes, q, id);
         else divide_and_quantize();
         // Q / idx: 64 steps of history in registers (lane l holds step t0 + l), one coalesced store every 64 steps
         auto commit = [&]() {
@@ -779,7 +781,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
-        ccur = in2n * p.inv_step;
+        in2cur = in2n;
         ++t;
         return true;
     };
@@ -880,7 +882,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
     load16(X0, xcol);
     load16(A0, acol);
     float n2cur = nrm[0];
-    float ccur = nrm[1] * p.inv_step;               // fl(1 / ||x_t||^2) * fl(1 / step): the constant of quant_msq_from_dot
+    float in2cur = nrm[1];                          // fl(1 / ||x_t||^2) for quant_msq_from_dot
     float qhist[RT];                                // Q / idx history: lane l holds step t0 + l, one register per row
     int ihist[RT];
 #pragma unroll
@@ -905,8 +907,8 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
         const int tn = more ? t + 1 : t;
         float wn[RT];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = wrow[r][tn];
-        const float n2n = nrm[2 * tn], in2n = nrm[2 * tn + 1];
+        for (int r = 0; r < RT; ++r) wn[r] = sload(wrow[r], 4u * (unsigned)tn);
+        const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
         // the RT row totals, row r parked in lane r, then ONE quantizer evaluation for all rows
         float v = 0.0f;
 #pragma unroll
@@ -922,7 +924,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
             const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
             q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)(grow0 + (lane < RT ? lane : 0)), (uint64_t)t, id);
         };
-        if (MODE == MODE_MSQ) redo = !quant_msq_from_dot(v, ccur, p.step, p.Kf, p.msq_thr, ~((1ull << RT) - 1ull), q, id);
+        if (MODE == MODE_MSQ) redo = !quant_msq_from_dot(v, in2cur, p.inv_step, p.step, p.Kf, p.msq_thr, ~((1ull << RT) - 1ull), q, id);
         else divide_and_quantize();
         auto commit = [&]() {
 #pragma unroll
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
         n2cur = n2n;
-        ccur = in2n * p.inv_step;
+        in2cur = in2n;
         ++t;
         return true;
     };

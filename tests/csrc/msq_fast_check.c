@@ -29,9 +29,9 @@ static float exact_form(float v, float n2, float step, float Kf, int* idx)
     return (sg * step) * r;
 }
 
-static int fast_form(float v, float c, float step, float Kf, float thr, float* q, int* idx)
+static int fast_form(float v, float in2, float inv_step, float step, float Kf, float thr, float* q, int* idx)
 {
-    const float r = v * c;
+    const float r = (v * in2) * inv_step;
     const float y = r + 0.5f;
     const float fl = floorf(y);
     const float d = (y - fl) - 0.5f;
@@ -84,11 +84,10 @@ int main(int argc, char** argv)
             }
             const float in2 = (n2 > 0.0f) ? 1.0f / n2 : 0.0f;
             const float inv_step = 1.0f / step;
-            const float c = in2 * inv_step;
             int ie, iq;
             float qf;
             const float qe = exact_form(v, n2, step, Kf, &ie);
-            const int ok = fast_form(v, c, step, Kf, 0.5f - (Kf + 4.0f) * TOL_UNIT, &qf, &iq);
+            const int ok = fast_form(v, in2, inv_step, step, Kf, 0.5f - (Kf + 4.0f) * TOL_UNIT, &qf, &iq);
             ++total;
             if (ok) {
                 ++okc;
@@ -103,7 +102,7 @@ int main(int argc, char** argv)
     {
         int ie, iq; float qf;
         const float qe = exact_form(0.0f, 0.0f, 0.1f, 8.0f, &ie);
-        const int ok = fast_form(0.0f, 0.0f, 0.1f, 8.0f, 0.5f - 12.0f * TOL_UNIT, &qf, &iq);
+        const int ok = fast_form(0.0f, 0.0f, 10.0f, 0.1f, 8.0f, 0.5f - 12.0f * TOL_UNIT, &qf, &iq);
         if (ok) ++bad;                 /* a zero dot product always takes the divisions */
         (void)qe; (void)ie;
     }
