@@ -154,7 +154,7 @@ def kernel_name(desc, mode=0):
     rt, waves = int(kv["RT"]), int(kv["waves"])
     if w[0] == "resident":
         if int(kv.get("S", "0")) == 1:
-            return "gpfq_wave_kernel<"
+            return "gpfq_resident_rt%d_m%d_w1" % (rt, mode)
         return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
         return "gpfq_coop_rt%d_m%d_w%d" % (rt, mode, 12 if rt == 1 else 8 if waves <= 8 else 16 if (rt == 2 and waves > 12) else 12)
@@ -179,7 +179,7 @@ def l2_column_bytes(desc, N, d, m_pad, groups=1):
     rt = int(kv["RT"])
     Ng = N // groups
     if w[0] == "resident" and int(kv.get("S", "0")) == 1:
-        tiles = groups * (-(-Ng // rt))           # wave kernel: one wave per RT rows
+        tiles = groups * (-(-Ng // rt))           # one-segment rows: one wave per RT rows
     else:
         tiles = groups * (-(-Ng // rt))
     return tiles * d * 8 * m_pad

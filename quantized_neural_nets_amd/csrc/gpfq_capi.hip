@@ -107,8 +107,15 @@ double slab_step_cost(int RT, int waves, int C, int wgs)
 // would idle whole CUs: a step costs the same however few rows the chip holds), within the register budget.
 int resident_rows_per_wg(int64_t Ng, int S, int cus)
 {
-    if (S <= 1) return 1;                                  // one-segment rows run on the wave kernel
     const int force = env_int("GPFQ_RESIDENT_RT", 0);
+    if (S <= 1) {
+        // one-segment rows (a workgroup is one wave, the step is that wave's instruction stream): one row per wave while
+        // every SIMD holds at most one wave, then rows share the wave -- the quantizer runs once per step for all of them
+        // (measured per column, N = 1152 / 2048 / 4096 / 8192 rows: one row 0.42 / 0.54 / 1.03 / 2.05 us, two rows
+        // 0.43 / 0.46 / 0.66 / 1.25, four rows 0.64 / 0.66 / 0.67 / 1.07)
+        if (force == 1 || force == 2 || force == 4) return force;
+        return Ng <= 5 * (int64_t)cus ? 1 : (Ng <= 16 * (int64_t)cus ? 2 : 4);
+    }
     const int cap = resident_max_rt(S);
     for (int rt = 4; rt >= 2; rt >>= 1)
         if (rt <= cap && (force ? rt == force : (Ng + rt - 1) / rt >= cus)) return rt;
@@ -430,6 +437,7 @@ SlabKernel resident_kernel(int RT, int mode, int maxw)
         }                                                                                                             \
     }
     GPFQ_PICK(1, 8) GPFQ_PICK(2, 8) GPFQ_PICK(4, 8) GPFQ_PICK(1, 12) GPFQ_PICK(2, 12) GPFQ_PICK(1, 16)
+    GPFQ_PICK(1, 1) GPFQ_PICK(2, 1) GPFQ_PICK(4, 1)
 #undef GPFQ_PICK
     return nullptr;
 }
@@ -440,7 +448,7 @@ int resident_max_rt(int waves) { return waves <= 8 ? 4 : (waves <= 12 ? 2 : 1); 
 int launch_resident(const Plan& pl, const gpfq::SlabParams& sp, int mode, int groups, hipStream_t st)
 {
     if (pl.waves != pl.S || pl.S > 16) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
-    const int maxw = pl.waves <= 8 ? 8 : (pl.waves <= 12 ? 12 : 16);
+    const int maxw = pl.S == 1 ? 1 : (pl.waves <= 8 ? 8 : (pl.waves <= 12 ? 12 : 16));     // 1: the one-segment variant
     SlabKernel k = resident_kernel(pl.RT, mode, maxw);
     if (!k) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no resident kernel for this (rows, waves) pair");
     const size_t shm = sizeof(float) * 2 * (size_t)pl.RT * (size_t)pl.S;
@@ -457,32 +465,6 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
 {
     const gpfq::SlabParams sp = make_slab_params(pl, p, vec, scratch);
     const int m = p.qc.mode;
-    if (pl.kind == GPFQ_PLAN_RESIDENT && pl.S == 1 && !env_int("GPFQ_NO_WAVE_KERNEL", 0)) {
-        // one wave per row tile; four rows per wave once there are more rows than the chip has wave slots for
-        // (the quantizer then runs once per four rows: the step is VALU-issue-bound at 16 waves per CU)
-        const int wrt = env_int("GPFQ_WAVE_RT", sp.Ng >= 4096 ? 4 : 1) == 4 ? 4 : 1;     // measured: 4096 rows 1.5x faster, 2048 rows 1.3x slower
-        dim3 grid((unsigned)((sp.Ng + 4 * wrt - 1) / (4 * wrt)), (unsigned)groups, 1);
-#define GPFQ_LAUNCH_WAVE(RTV, MODEV) hipLaunchKernelGGL((gpfq::gpfq_wave_kernel<RTV, MODEV>), grid, dim3(256), 0, st, sp)
-        if (wrt == 4) {
-            switch (m) {
-            case gpfq::MODE_SOFT: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_SOFT); break;
-            case gpfq::MODE_HARD: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_HARD); break;
-            case gpfq::MODE_STOCHASTIC: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_STOCHASTIC); break;
-            default: GPFQ_LAUNCH_WAVE(4, gpfq::MODE_MSQ); break;
-            }
-        } else {
-            switch (m) {
-            case gpfq::MODE_SOFT: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_SOFT); break;
-            case gpfq::MODE_HARD: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_HARD); break;
-            case gpfq::MODE_STOCHASTIC: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_STOCHASTIC); break;
-            default: GPFQ_LAUNCH_WAVE(1, gpfq::MODE_MSQ); break;
-            }
-        }
-#undef GPFQ_LAUNCH_WAVE
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "GPFQ wave kernel launch");
-        return GPFQ_OK;
-    }
     if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_resident(pl, sp, m, groups, st);
     return launch_coop(pl, sp, m, scratch, st);
 }

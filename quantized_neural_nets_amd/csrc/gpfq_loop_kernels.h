@@ -1,6 +1,6 @@
-// gpfq_loop_kernels.h -- the GPFQ loop kernels (gfx950): gpfq_resident_kernel (residual resident in registers, whole
-// rows per workgroup), gpfq_coop_kernel (the same with rows split over co-operating workgroups), gpfq_wave_kernel
-// (one-segment rows, one wave per row tile) and gpfq_stream_kernel (residual streamed through HBM / L2).  Reference: StepAlgorithm._quantization,
+// gpfq_loop_kernels.h -- the GPFQ loop kernels (gfx950): gpfq_resident_* (residual resident in registers, whole rows per
+// workgroup; _w1 = one-segment rows, a workgroup of one wave), gpfq_coop_* (the same with rows split over co-operating
+// workgroups) and gpfq_stream_kernel (residual streamed through HBM / L2).  Reference: StepAlgorithm._quantization,
 // step_algorithm.py:107-148.  One launch runs the WHOLE column loop of a layer (all groups): rows of the residual U
 // are independent, and per step a workgroup makes ONE pass over its rows, fusing
 //   u -= q_{t-1} x_{t-1};  u += w_t a_t;  <u, x_t>.
@@ -590,7 +590,9 @@ GPFQ_DEFINE_COOP_MODES(2, 16, 1, 48, "v127")
 // ------------------------------------------------------------------------------------------------
 // WB = first register of the window = the kernel's register budget minus 80 + 16 RT (see GPFQ_DEFINE_RESIDENT below):
 // three x buffers, two a buffers, then the RT residual rows.
-template <int RT, int MODE, int WB>
+// ONE = rows of a single segment (m <= 1024: every fully connected layer, 1x1 convs on 1x1 maps): the workgroup is one
+// wave, the lane tree's total IS the dot product -- no LDS word, no barrier, no slot tree.
+template <int RT, int MODE, int WB, bool ONE = false>
 __device__ __forceinline__ void resident_body(const SlabParams& p)
 {
     static_assert(RT == 1 || RT == 2 || RT == 4, "one DPP row of 16 lanes per residual row");
@@ -690,12 +692,15 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         }
         win_load4<XP, 0>(xload, lane_off);
         win_load4<AC, 0>(aload, lane_off);
+        float v1 = 0.0f;                            // ONE: the dot products, row r in lane row r
         if constexpr (RT == 1) {
             const float sg = wave_tree64_lane63(acc[0]);
-            if (lane == 63) seg[wave] = sg;
+            if constexpr (ONE) v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg), 63));
+            else if (lane == 63) seg[wave] = sg;
         } else {                                    // row r's total in lane row r: one LDS write for all rows
             const float tot = wave_tree64_rows<RT>(acc);
-            if ((lane & 15) == 0 && r16 < RT) seg[r16 * S + wave] = tot;
+            if constexpr (ONE) v1 = tot;
+            else if ((lane & 15) == 0 && r16 < RT) seg[r16 * S + wave] = tot;
         }
         float uni = 0.0f;
         if (MODE == MODE_STOCHASTIC)
@@ -703,14 +708,19 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         win_load4<XP, 1>(xload, lane_off);
         win_load4<AC, 1>(aload, lane_off);
         GPFQ_RSTAMP(3)
-        __syncthreads();
+        if constexpr (!ONE) __syncthreads();
         GPFQ_RSTAMP(4)
         win_load4<XP, 2>(xload, lane_off);
         win_load4<AC, 2>(aload, lane_off);
         // the slot tree in every wave, all RT rows at once: lane = 16 * row + slot; the other lanes hold +0.0f, so the
         // four levels need no tests
-        const float val = seg[seg_off];
-        const float v = wave_tree16_zero_padded(occupied ? val : 0.0f);
+        float v;
+        if constexpr (ONE) {
+            v = v1;
+        } else {
+            const float val = seg[seg_off];
+            v = wave_tree16_zero_padded(occupied ? val : 0.0f);
+        }
         // Next column's weights and norm through the scalar cache (the last step re-reads its own, unused, ones rather
         // than branch) -- requested HERE, behind the LDS read: scalar loads and LDS share one counter (lgkmcnt) and
         // return out of order, so every wait on that counter is a wait for all of them; requested at the top of the
@@ -841,154 +851,25 @@ GPFQ_DEFINE_RESIDENT_MODES(4, 8, 112, "v255")
 GPFQ_DEFINE_RESIDENT_MODES(1, 12, 72, "v167")
 GPFQ_DEFINE_RESIDENT_MODES(2, 12, 56, "v167")
 GPFQ_DEFINE_RESIDENT_MODES(1, 16, 32, "v127")
+// one-segment rows: a workgroup is one wave (same budgets as the 8-wave variants)
+#define GPFQ_DEFINE_RESIDENT_ONE(RT, MODE, WB)                                                                    \
+    __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(WB / 2)))                                \
+    gpfq_resident_rt##RT##_m##MODE##_w1(const SlabParams p)                                                      \
+    {                                                                                                             \
+        asm volatile("" ::: "v255");                                                                              \
+        resident_body<RT, MODE, WB, true>(p);                                                                     \
+    }
+#define GPFQ_DEFINE_RESIDENT_ONE_MODES(RT, WB)                                                                    \
+    GPFQ_DEFINE_RESIDENT_ONE(RT, 0, WB) GPFQ_DEFINE_RESIDENT_ONE(RT, 1, WB) GPFQ_DEFINE_RESIDENT_ONE(RT, 2, WB)    \
+    GPFQ_DEFINE_RESIDENT_ONE(RT, 3, WB)
+GPFQ_DEFINE_RESIDENT_ONE_MODES(1, 160)
+GPFQ_DEFINE_RESIDENT_ONE_MODES(2, 144)
+GPFQ_DEFINE_RESIDENT_ONE_MODES(4, 112)
 
 // ------------------------------------------------------------------------------------------------
 // Streaming plan: any (N, m).  The residual rows stay in the caller's U (HBM / L2 / Infinity Cache) and
 // are read and written once per step; wave w owns segments w, w+NW, ... of the workgroup's RT rows.
 // ------------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------------
-// One-segment rows (m <= 1024: every fully connected layer, 1x1 convs on 1x1 maps, small depthwise maps):
-// the whole row lives in ONE wave, so the step needs no LDS and no barrier at all -- sweep, lane tree,
-// v_readlane, quantize, next step.  A workgroup is just four independent waves; Q / idx are kept 64 steps in
-// registers (lane l holds step t0 + l) and leave as one coalesced store per row.
-// ------------------------------------------------------------------------------------------------
-template <int RT, int MODE>
-__global__ void __launch_bounds__(256) gpfq_wave_kernel(const SlabParams p)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.y;
-    const int row0 = (blockIdx.x * 4 + wave) * RT;  // first row of this wave's tile, inside the group
-    if (row0 >= p.Ng) return;                       // whole wave leaves: nothing is shared between waves
-    const int64_t grow0 = (int64_t)g * p.Ng + row0;
-    const int64_t kbase = 4 * lane;
-    const float* __restrict__ acol = p.AT + (int64_t)g * p.d * p.m_pad + kbase;
-    const float* __restrict__ xcol = p.XT + (int64_t)g * p.d * p.m_pad + kbase;
-    const kfloat* nrm = as_scalar(p.nrm2 + 2 * (int64_t)g * p.d);
-
-    float u[RT][16], X0[16], X1[16], A0[16];
-    const kfloat* wrow[RT];
-    float qprev[RT], wcur[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        wrow[r] = as_scalar(p.W + (grow0 + ((row0 + r < p.Ng) ? r : 0)) * p.ldw);   // rows past the end duplicate the first
-#pragma unroll
-        for (int e = 0; e < 16; ++e) u[r][e] = 0.0f;
-        qprev[r] = 0.0f;
-        wcur[r] = wrow[r][0];
-    }
-    // x_t alternates between X0 and X1 (no copies), a_t lives in A0; X1 starts as x_{-1} = 0 (q_{-1} = 0)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) X1[e] = 0.0f;
-    load16(X0, xcol);
-    load16(A0, acol);
-    float n2cur = nrm[0];
-    float in2cur = nrm[1];                          // fl(1 / ||x_t||^2) for quant_msq_from_dot
-    float qhist[RT];                                // Q / idx history: lane l holds step t0 + l, one register per row
-    int ihist[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) { qhist[r] = 0.0f; ihist[r] = 0; }
-    int t = 0;
-    // one step; xprev = x_{t-1}, xcur = x_t.  Returns false after the last column.
-    auto step = [&](float (&xprev)[16], float (&xcur)[16]) -> bool {
-        const bool more = t + 1 < p.d;
-        float acc[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) acc[r] = sweep16<true>(u[r], xprev, A0, xcur, qprev[r], wcur[r]);
-        // next column into the registers the sweep has just finished with (x_{t-1}'s and a_t's), issued right behind
-        // the sweep (its latency hides under the reduction and the quantizer); the opaque asm keeps it from being
-        // hoisted above the sweep, and it is unconditional (the last step re-reads its own column) so that no join
-        // copy and no branch is needed
-        int64_t adv = more ? p.m_pad : 0;
-        asm volatile("" : "+s"(adv) : "v"(acc[0]));
-        xcol += adv;
-        acol += adv;
-        load16(xprev, xcol);
-        load16(A0, acol);
-        const int tn = more ? t + 1 : t;
-        float wn[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) wn[r] = sload(wrow[r], 4u * (unsigned)tn);
-        const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
-        // the RT row totals, row r parked in lane r, then ONE quantizer evaluation for all rows
-        float v = 0.0f;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            const float sg = wave_tree64_lane63(acc[r]);
-            const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sg), 63));
-            if (lane == r) v = tot;
-        }
-        int id;
-        float q;
-        bool redo = false;                          // use first, check second: see resident_body
-        auto divide_and_quantize = [&]() {
-            const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
-            q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)(grow0 + (lane < RT ? lane : 0)), (uint64_t)t, id);
-        };
-        if (MODE == MODE_MSQ) redo = !quant_msq_from_dot(v, in2cur, p.inv_step, p.step, p.Kf, p.msq_thr, ~((1ull << RT) - 1ull), q, id);
-        else divide_and_quantize();
-        auto commit = [&]() {
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                qprev[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, q), r));
-                const int idr = __builtin_amdgcn_readlane(id, r);
-                if (lane == (t & 63)) { qhist[r] = qprev[r]; ihist[r] = idr; }
-            }
-        };
-        commit();
-        if (MODE == MODE_MSQ && __builtin_expect(redo, 0)) {
-            divide_and_quantize();
-            commit();
-        }
-        if (__builtin_expect((t & 63) == 63 || !more, 0)) {
-            const int t0 = t & ~63;
-            if (lane <= t - t0) {
-#pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    if (row0 + r < p.Ng) {
-                        const int64_t gw = grow0 + r;
-                        p.Q[gw * p.ldq + t0 + lane] = qhist[r];
-                        if (p.idx) {
-                            if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)ihist[r];
-                            else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)ihist[r];
-                        }
-                    }
-                }
-            }
-        }
-        if (!more) return false;
-#pragma unroll
-        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
-        n2cur = n2n;
-        in2cur = in2n;
-        ++t;
-        return true;
-    };
-    int k = 0;                                       // buffer that holds x_{d-1} when the loop ends
-    for (;;) {
-        k = 0; if (!step(X1, X0)) break;
-        k = 1; if (!step(X0, X1)) break;
-    }
-    // pending subtraction of the last step, then the residual leaves the registers (step_algorithm.py:148)
-    auto finish = [&](const float (&xlast)[16]) {
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pq = qprev[r] * xlast[e];
-                u[r][e] = u[r][e] - pq;
-            }
-            if (row0 + r < p.Ng) {
-                float* Urow = p.U + (grow0 + r) * p.ldu;
-                if (p.vec) store_u16<true>(u[r], Urow, kbase, p.m);
-                else store_u16<false>(u[r], Urow, kbase, p.m);
-                if (p.usq) store_segment_sumsq(p.usq, grow0 + r, u[r], lane);      // one-segment rows: S == 1
-            }
-        }
-    };
-    if (k == 0) finish(X0);
-    else finish(X1);
-}
-
 struct StreamCoop {
     int C;                              // members per row tile (1 = every workgroup owns whole rows)
     int tiles;                          // row tiles

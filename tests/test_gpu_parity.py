@@ -235,15 +235,18 @@ def test_eight_gpu_shard_shapes_of_long_rows(qnn, oracle_mod, N, expect):
         assert torch.equal(r2["idx"], r["idx"]) and torch.equal(r2["U"], r["U"])
 
 
-@pytest.mark.parametrize("wrt", [1, 4])
-def test_one_segment_rows_wave_kernel(qnn, oracle_mod, monkeypatch, wrt):
-    """m <= 1024 (fully connected layers): one wave per row tile, 1 or 4 rows per wave, ragged last tile, history
-    flush across 64-step blocks, grouped."""
-    for (N, d, m, groups, reg) in [(13, 150, 700, 1, None), (9, 70, 1024, 3, "L0")]:
+@pytest.mark.parametrize("rt", [1, 2, 4])
+def test_one_segment_rows(qnn, oracle_mod, monkeypatch, rt):
+    """m <= 1024 (fully connected layers): a workgroup is one wave of the resident kernel's one-segment variant -- no LDS,
+    no barrier -- with 1, 2 or 4 rows per wave: ragged last tile, history flush across 64-step blocks, grouped, all
+    four quantizers (the stochastic one against the oracle's Philox stream)."""
+    from quantized_neural_nets_amd import _lib
+    for (N, d, m, groups, reg) in [(13, 150, 700, 1, None), (9, 70, 1024, 3, "L0"), (7, 65, 333, 1, "L1")]:
         case = dict(name="wave", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg=reg, lamb=0.02, groups=groups,
                     first_layer=False, zero_every=9, seed=12)
         W, A, X = gi.make_inputs(case)
-        monkeypatch.setenv("GPFQ_WAVE_RT", str(wrt))
+        monkeypatch.setenv("GPFQ_RESIDENT_RT", str(rt))
+        assert _lib.describe_plan(N, d, m, groups).startswith("resident RT=%d waves=1 S=1" % rt)
         r = _run_layer(qnn, case, W, A, X, 0)
         o = oracle_mod.quantize_layer(W, A, X, 1.16 / 8, 8, 1.0, reg, 0.02, groups)
         assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])

@@ -28,8 +28,9 @@ def main():
     for ci in range(ncases):
         fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped"])
         groups = 1
-        if fam == "wave":
+        if fam == "wave":                           # one-segment rows: the resident kernel's one-wave variant, 1 / 2 / 4 rows per wave
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
+            os.environ["GPFQ_RESIDENT_RT"] = str(int(rng.choice([1, 2, 4])))
         elif fam == "resident":
             N, m = int(rng.integers(1, 40)), int(rng.integers(1025, 16385))
             # rows per workgroup: forced, so that the 2- and 4-row kernels (chosen on their own only from 512 rows on) and
