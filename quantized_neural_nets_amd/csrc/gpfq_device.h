@@ -481,6 +481,46 @@ __device__ __forceinline__ float win_sweep16(float q, float w)
 #undef GPFQ_S
     return acc;
 }
+// The sweep of TWO residual rows at once, their registers interleaved (UP + 2k = element k of the first row, UP + 2k + 1
+// of the second): every instruction serves one element of BOTH rows, so the dot products' fma chains pack as well --
+// v_pk_fma_f32, each half a fused multiply-add of its own row -- and a pair of rows costs 80 instructions instead of 96.
+// The same five individually rounded operations per element and row, in the same order; {q0, q1} and {w0, w1} travel as
+// register pairs, op_sel broadcasts element k of the column pair register to both halves.
+#define GPFQ_SP(u0, u1, kb, kb1, sel)                                                                                \
+    "v_pk_mul_f32 %1, %3, v[%c6+" #kb ":%c6+" #kb1 "] op_sel:[0," #sel "] op_sel_hi:[1," #sel "]\n\t"                 \
+    "v_pk_mul_f32 %2, %4, v[%c7+" #kb ":%c7+" #kb1 "] op_sel:[0," #sel "] op_sel_hi:[1," #sel "]\n\t"                 \
+    "v_pk_add_f32 v[%c5+" #u0 ":%c5+" #u1 "], v[%c5+" #u0 ":%c5+" #u1 "], %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"           \
+    "v_pk_add_f32 v[%c5+" #u0 ":%c5+" #u1 "], v[%c5+" #u0 ":%c5+" #u1 "], %2\n\t"                                     \
+    "v_pk_fma_f32 %0, v[%c5+" #u0 ":%c5+" #u1 "], v[%c8+" #kb ":%c8+" #kb1 "], %0 op_sel:[0," #sel ",0] op_sel_hi:[1," #sel ",1]\n\t"
+template <int UP, int XP, int A, int X>
+__device__ __forceinline__ v2f win_sweep16_pair(float q0, float q1, float w0, float w1)
+{
+    v2f acc = {0.0f, 0.0f};
+    v2f t0, t1;
+    const v2f qq = {q0, q1}, ww = {w0, w1};
+    asm volatile(
+    GPFQ_SP(0, 1, 0, 1, 0)
+    GPFQ_SP(2, 3, 0, 1, 1)
+    GPFQ_SP(4, 5, 2, 3, 0)
+    GPFQ_SP(6, 7, 2, 3, 1)
+    GPFQ_SP(8, 9, 4, 5, 0)
+    GPFQ_SP(10, 11, 4, 5, 1)
+    GPFQ_SP(12, 13, 6, 7, 0)
+    GPFQ_SP(14, 15, 6, 7, 1)
+    GPFQ_SP(16, 17, 8, 9, 0)
+    GPFQ_SP(18, 19, 8, 9, 1)
+    GPFQ_SP(20, 21, 10, 11, 0)
+    GPFQ_SP(22, 23, 10, 11, 1)
+    GPFQ_SP(24, 25, 12, 13, 0)
+    GPFQ_SP(26, 27, 12, 13, 1)
+    GPFQ_SP(28, 29, 14, 15, 0)
+    GPFQ_SP(30, 31, 14, 15, 1)
+                 "s_nop 1"
+                 : "+v"(acc), "=&v"(t0), "=&v"(t1)
+                 : "v"(qq), "v"(ww), "n"(UP), "n"(XP), "n"(A), "n"(X));
+    return acc;
+}
+#undef GPFQ_SP
 // the pending subtraction of the last step, in place: u = u - q * x_{d-1}                          (step_algorithm.py:148)
 template <int U, int XL>
 __device__ __forceinline__ void win_final_sub16(float q)
@@ -497,6 +537,24 @@ template <int B>
 __device__ __forceinline__ void win_read4(float (&d)[4])
 {
     asm volatile("v_mov_b32 %0, v[%c4+0]\n\tv_mov_b32 %1, v[%c4+1]\n\tv_mov_b32 %2, v[%c4+2]\n\tv_mov_b32 %3, v[%c4+3]\n\ts_nop 0"
+                 : "=v"(d[0]), "=v"(d[1]), "=v"(d[2]), "=v"(d[3]) : "n"(B));
+}
+// the same two helpers for ONE row of an interleaved pair (its registers are B, B + 2, B + 4, ...)
+template <int U, int XL>
+__device__ __forceinline__ void win_final_sub16_s2(float q)
+{
+    float t;
+#define GPFQ_F(e, u) "v_mul_f32 %0, %1, v[%c3+" #e "]\n\tv_sub_f32 v[%c2+" #u "], v[%c2+" #u "], %0\n\t"
+    asm volatile(GPFQ_F(0, 0) GPFQ_F(1, 2) GPFQ_F(2, 4) GPFQ_F(3, 6) GPFQ_F(4, 8) GPFQ_F(5, 10) GPFQ_F(6, 12) GPFQ_F(7, 14)
+                 GPFQ_F(8, 16) GPFQ_F(9, 18) GPFQ_F(10, 20) GPFQ_F(11, 22) GPFQ_F(12, 24) GPFQ_F(13, 26) GPFQ_F(14, 28)
+                 GPFQ_F(15, 30) "s_nop 0"
+                 : "=&v"(t) : "v"(q), "n"(U), "n"(XL));
+#undef GPFQ_F
+}
+template <int B>
+__device__ __forceinline__ void win_read4_s2(float (&d)[4])
+{
+    asm volatile("v_mov_b32 %0, v[%c4+0]\n\tv_mov_b32 %1, v[%c4+2]\n\tv_mov_b32 %2, v[%c4+4]\n\tv_mov_b32 %3, v[%c4+6]\n\ts_nop 0"
                  : "=v"(d[0]), "=v"(d[1]), "=v"(d[2]), "=v"(d[3]) : "n"(B));
 }
 

@@ -142,7 +142,8 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
     const int member = lane & ((1 << sh) - 1);
     {
         const unsigned epoch = (unsigned)t + 1u;
-        unsigned long long* xb_ = p.xbuf + ((size_t)(tile * 2 + par) * C) * RT;
+        // (32-bit offset arithmetic: the exchange area is 96 KiB; as size_t this was four 64-bit multiplies per step)
+        unsigned long long* xb_ = p.xbuf + (unsigned)(tile * 2 + par) * (unsigned)(C * RT);
         if ((lane & 15) == 0 && (lane >> 4) < RT)
             __hip_atomic_store(xb_ + (size_t)c * RT + (lane >> 4),
                                ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
@@ -151,11 +152,12 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         const unsigned long long* src = xb_ + (want ? (size_t)(wide ? 2 * member : member) * RT + gr_ : 0);
         unsigned long long gv = 0, gw = 0;
         unsigned spins = 0;
+        // lanes that gather nothing count as arrived; the compare mask goes straight into the scalar unit
+        const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
         if (!wide) {
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = !want || ((unsigned)(gv >> 32) == epoch);
-                if (__all(ok)) break;
+                if ((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) | idle) == __builtin_amdgcn_read_exec()) break;
                 if (++spins > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -165,8 +167,8 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 gw = __hip_atomic_load(src1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool ok = !want || ((unsigned)(gv >> 32) == epoch && (unsigned)(gw >> 32) == epoch);
-                if (__all(ok)) break;
+                if (((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) &
+                      __builtin_amdgcn_ballot_w64((unsigned)(gw >> 32) == epoch)) | idle) == __builtin_amdgcn_read_exec()) break;
                 if (++spins > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -255,10 +257,12 @@ __device__ __forceinline__ void store_segment_sumsq(float* usq, int64_t slot, co
 
 // Tail of the window kernels for one row: the pending subtraction of the last step (in place, in the window), then the
 // residual leaves the registers four elements at a time (step_algorithm.py:148), with the fused sum of squares.
-template <int U, int XL>
+// STRIDE 2: the row is one of an interleaved pair (win_sweep16_pair): its registers are U, U + 2, U + 4, ...
+template <int U, int XL, int STRIDE = 1>
 __device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, bool valid, int64_t grow, int seg, int lane)
 {
-    win_final_sub16<U, XL>(qlast);
+    if constexpr (STRIDE == 1) win_final_sub16<U, XL>(qlast);
+    else win_final_sub16_s2<U, XL>(qlast);
     if (!valid) return;
     const int64_t kbase = (int64_t)seg * kSeg + 4 * lane;      // computed here: nothing 64-bit stays live across the loop
     float* Urow = p.U + grow * p.ldu;
@@ -266,7 +270,8 @@ __device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, b
     auto chunk = [&](auto c_) {
         constexpr int c = decltype(c_)::value;
         float v[4];
-        win_read4<U + 4 * c>(v);
+        if constexpr (STRIDE == 1) win_read4<U + 4 * c>(v);
+        else win_read4_s2<U + 8 * c>(v);
         const int64_t k0 = kbase + 256 * c;
         if (p.vec && k0 + 3 < p.m) {
             *reinterpret_cast<float4*>(Urow + k0) = make_float4(v[0], v[1], v[2], v[3]);
@@ -429,11 +434,15 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         if (active) {
             win_wait<DEPTH == 2 ? 8 : 0>();         // column t has landed (DEPTH 2: the loads of column t+1 stay in flight)
             float acc[RT];
-            acc[0] = win_sweep16<U0, XP, AC, XC>(qprev[0], wcur[0]);
-            if constexpr (RT >= 2) acc[1] = win_sweep16<U0 + 16, XP, AC, XC>(qprev[1], wcur[1]);
-            if constexpr (RT >= 4) {
-                acc[2] = win_sweep16<U0 + 32, XP, AC, XC>(qprev[2], wcur[2]);
-                acc[3] = win_sweep16<U0 + 48, XP, AC, XC>(qprev[3], wcur[3]);
+            if constexpr (RT == 1) {
+                acc[0] = win_sweep16<U0, XP, AC, XC>(qprev[0], wcur[0]);
+            } else {                                // rows in interleaved pairs: 80 instructions per pair instead of 96
+                const v2f a01 = win_sweep16_pair<U0, XP, AC, XC>(qprev[0], qprev[1], wcur[0], wcur[1]);
+                acc[0] = a01.x; acc[1] = a01.y;
+                if constexpr (RT >= 4) {
+                    const v2f a23 = win_sweep16_pair<U0 + 32, XP, AC, XC>(qprev[2], qprev[3], wcur[2], wcur[3]);
+                    acc[2] = a23.x; acc[3] = a23.y;
+                }
             }
             GPFQ_STAMP(1)
             if constexpr (RT == 1) {
@@ -535,11 +544,15 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
     if (dead || !active) return;
     auto finish = [&](auto xl_) {
         constexpr int XL = decltype(xl_)::value;
-        finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, myseg, lane);
-        if constexpr (RT >= 2) finish_row_w<U0 + 16, XL>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, myseg, lane);
-        if constexpr (RT >= 4) {
-            finish_row_w<U0 + 32, XL>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, myseg, lane);
-            finish_row_w<U0 + 48, XL>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, myseg, lane);
+        if constexpr (RT == 1) {
+            finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, myseg, lane);
+        } else {                                    // interleaved pairs: row r sits at U0 + 32 (r / 2) + (r % 2), stride 2
+            finish_row_w<U0, XL, 2>(p, qprev[0], row0 < p.Ng, grow0, myseg, lane);
+            finish_row_w<U0 + 1, XL, 2>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, myseg, lane);
+            if constexpr (RT >= 4) {
+                finish_row_w<U0 + 32, XL, 2>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, myseg, lane);
+                finish_row_w<U0 + 33, XL, 2>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, myseg, lane);
+            }
         }
     };
     if (k == 0) finish(I0{});
@@ -676,11 +689,15 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         win_wait<8>();                              // column t has landed; the eight loads of column t+1 stay in flight
         GPFQ_RSTAMP(1)
         float acc[RT];
-        acc[0] = win_sweep16<U0, XP, AC, XC>(qprev[0], wcur[0]);
-        if constexpr (RT >= 2) acc[1] = win_sweep16<U0 + 16, XP, AC, XC>(qprev[1], wcur[1]);
-        if constexpr (RT >= 4) {
-            acc[2] = win_sweep16<U0 + 32, XP, AC, XC>(qprev[2], wcur[2]);
-            acc[3] = win_sweep16<U0 + 48, XP, AC, XC>(qprev[3], wcur[3]);
+        if constexpr (RT == 1) {
+            acc[0] = win_sweep16<U0, XP, AC, XC>(qprev[0], wcur[0]);
+        } else {                                    // rows in interleaved pairs: 80 instructions per pair instead of 96
+            const v2f a01 = win_sweep16_pair<U0, XP, AC, XC>(qprev[0], qprev[1], wcur[0], wcur[1]);
+            acc[0] = a01.x; acc[1] = a01.y;
+            if constexpr (RT >= 4) {
+                const v2f a23 = win_sweep16_pair<U0 + 32, XP, AC, XC>(qprev[2], qprev[3], wcur[2], wcur[3]);
+                acc[2] = a23.x; acc[3] = a23.y;
+            }
         }
         GPFQ_RSTAMP(2)
         // column t+2 goes into the registers the sweeps have just finished with (x_{t-1}'s and a_t's); the last two
@@ -816,11 +833,15 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
     win_wait<0>();
     auto finish = [&](auto xl_) {
         constexpr int XL = decltype(xl_)::value;
-        finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, wave, lane);
-        if constexpr (RT >= 2) finish_row_w<U0 + 16, XL>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, wave, lane);
-        if constexpr (RT >= 4) {
-            finish_row_w<U0 + 32, XL>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, wave, lane);
-            finish_row_w<U0 + 48, XL>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, wave, lane);
+        if constexpr (RT == 1) {
+            finish_row_w<U0, XL>(p, qprev[0], row0 < p.Ng, grow0, wave, lane);
+        } else {                                    // interleaved pairs: row r sits at U0 + 32 (r / 2) + (r % 2), stride 2
+            finish_row_w<U0, XL, 2>(p, qprev[0], row0 < p.Ng, grow0, wave, lane);
+            finish_row_w<U0 + 1, XL, 2>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, wave, lane);
+            if constexpr (RT >= 4) {
+                finish_row_w<U0 + 32, XL, 2>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, wave, lane);
+                finish_row_w<U0 + 33, XL, 2>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, wave, lane);
+            }
         }
     };
     if (k == 0) finish(I0{});
