@@ -349,6 +349,14 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.msq_thr = 0.5f - (p.qc.Kf + 4.0f) * 0x1p-18f;
     sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
+    // Exchange pacing (s_sleep 1 = 64 clocks each).  A poll that comes back without every granule costs a whole round
+    // trip AND sits in the way of the granules still travelling: the first poll waits for about the time the slowest
+    // member's store needs where 8 or more members are awaited (measured per column: 197-segment rows, 32 members x 4
+    // rows, 93 -> 72 us at 8 pauses; 181 segments, 16 members, 6.1 -> 5.7; 91 segments, 8 members x 4 rows, 2.84 ->
+    // 2.77; with 4 members any pause costs, 2-6 % over a whole layer).  The gap between two polls makes no difference
+    // that survives a whole-workload run (1 / 2 / 4 / 8 pauses: +- 1 %).
+    sp.poll_delay = env_int("GPFQ_COOP_POLL_DELAY", pl.C <= 4 ? 0 : 8);
+    sp.poll_gap = env_int("GPFQ_COOP_POLL_GAP", 1);
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     return sp;

@@ -94,6 +94,8 @@ struct SlabParams {
     int Ng, d, S, C, tiles, idx_bytes, vec;
     int pace;          // cooperative kernels: pauses (s_sleep 1 each) between the column requests issued in the exchange window; 0 = off
     int xcd_tiles;     // cooperative kernels: keep the members of a row tile on one XCD (needs tiles % 8 == 0)
+    int poll_delay;    // cooperative kernels: pauses (s_sleep 1 each) between publishing and the first poll
+    int poll_gap;      // ... and between two polls
     float step, Kf, lamb;
     float inv_step;    // fl(1 / step) for quant_msq_from_dot; NaN switches the division-free path off
     float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
@@ -154,12 +156,13 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         unsigned spins = 0;
         // lanes that gather nothing count as arrived; the compare mask goes straight into the scalar unit
         const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
+        for (int i = 0; i < p.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
         if (!wide) {
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) | idle) == __builtin_amdgcn_read_exec()) break;
                 if (++spins > p.spin_limit) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                for (int i = 0; i < p.poll_gap; ++i) __builtin_amdgcn_s_sleep(1);
             }
             v = want ? __uint_as_float((unsigned)gv) : 0.0f;
         } else {
@@ -170,7 +173,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                 if (((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) &
                       __builtin_amdgcn_ballot_w64((unsigned)(gw >> 32) == epoch)) | idle) == __builtin_amdgcn_read_exec()) break;
                 if (++spins > p.spin_limit) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                for (int i = 0; i < p.poll_gap; ++i) __builtin_amdgcn_s_sleep(1);
             }
             v = want ? __uint_as_float((unsigned)gv) + __uint_as_float((unsigned)gw) : 0.0f;
         }
