@@ -98,8 +98,11 @@ int pow2_ceil_host(int v)
 double slab_step_cost(int RT, int waves, int C, int wgs)
 {
     const int n = RT * C;
-    return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.28 + 1.02 * wgs / 256.0 : 0.0) + (C >= 32 ? 0.65 : 0.0) +
-           (C >= 64 ? 1.5 : 0.0) + (((RT == 4 && waves > 8) || (RT == 2 && waves > 12)) ? 0.43 : 0.0);
+    (void)wgs;
+    // (the gather terms were 0.28 + 1.02 wgs/256, 0.65 and 1.5 before the first poll was paced -- launch_coop -- and the
+    // reducer went on its instruction diet; re-measured on the shapes that run in rounds: 50 segments 4 rows x 8 members
+    // 2.35 us, 197 segments 4 x 32 2.26, 785 segments 2 x 64 3.45; 91 segments 2 x 8 2.20 against 4 x 16 2.50)
+    return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.25 + 0.005 * (n - 16) : 0.0) + (C >= 32 ? 0.1 : 0.0) + (C >= 64 ? 0.9 : 0.0) + (((RT == 4 && waves > 8) || (RT == 2 && waves > 12)) ? 0.43 : 0.0);
 }
 
 // Rows per workgroup of the resident plan: the rows of a workgroup share every column load, and the CU's vector-memory

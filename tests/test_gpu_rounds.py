@@ -27,7 +27,8 @@ def _run(W, A, X, m, plan, mode="msq", seed=None, K=8, step=None):
 CASES = [
     ((300, 24, 51200), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "8"}, "coop RT=4 C=8 waves=7 S=50 grid=256 rounds=3",
      "three rounds, the last one partial (44 rows)"),
-    ((300, 24, 51200), {}, "coop RT=2 C=4 waves=13 S=50 grid=256 rounds=3", "two rows x 13 sweep waves: the 16-wave variant"),
+    ((300, 24, 51200), {"GPFQ_COOP_RT": "2", "GPFQ_COOP_C": "4"}, "coop RT=2 C=4 waves=13 S=50 grid=256 rounds=3",
+     "two rows x 13 sweep waves: the 16-wave variant"),
     ((70, 16, 201728), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "32"}, "coop RT=4 C=32 waves=7 S=197 grid=256 rounds=3",
      "128 granules: two gathered members per lane; the last tile has 2 valid rows"),
     ((21, 10, 803840), {}, "coop RT=2 C=64 waves=13 S=785 grid=256 rounds=3", "16-wave variant AND 128 granules, odd row count"),

@@ -72,7 +72,7 @@ def test_plan_selection(lib):
     assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=4 C=2 waves=7")      # long rows, more rows than CUs
     assert lib.describe_plan(64, 9, 30000, 64).startswith("stream")                     # grouped: never cooperative
     # long rows, more of them than the chip holds: cooperative in rounds (one co-resident launch per block of rows)
-    assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=2 C=4 waves=13 S=50 grid=256 rounds=16")
+    assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=4 C=8 waves=7 S=50 grid=256 rounds=16")
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=32 waves=7 S=197 grid=256 rounds=32")   # 128 granules
     assert lib.describe_plan(256, 64, 803840).startswith("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32")    # 16-wave variant
     assert lib.describe_plan(2048, 512, 13312).startswith("resident RT=1 waves=13")     # <= 16 segments: whole rows, no exchange
