@@ -101,8 +101,9 @@ double slab_step_cost(int RT, int waves, int C, int wgs)
     (void)wgs;
     // (the gather terms were 0.28 + 1.02 wgs/256, 0.65 and 1.5 before the first poll was paced -- launch_coop -- and the
     // reducer went on its instruction diet; re-measured on the shapes that run in rounds: 50 segments 4 rows x 8 members
-    // 2.35 us, 197 segments 4 x 32 2.26, 785 segments 2 x 64 3.45; 91 segments 2 x 8 2.20 against 4 x 16 2.50)
-    return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.25 + 0.005 * (n - 16) : 0.0) + (C >= 32 ? 0.1 : 0.0) + (C >= 64 ? 0.9 : 0.0) + (((RT == 4 && waves > 8) || (RT == 2 && waves > 12)) ? 0.43 : 0.0);
+    // 2.35 us, 197 segments 4 x 32 2.26, 785 segments 2 x 64 3.45; 91 segments 2 x 8 2.20 against 4 x 16 2.50, and a
+    // 32-row shard of them 1 x 8 2.06 against 2 x 16 2.26)
+    return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.45 + 0.004 * (n - 16) : 0.0) + (C >= 32 ? 0.1 : 0.0) + (C >= 64 ? 0.9 : 0.0) + (((RT == 4 && waves > 8) || (RT == 2 && waves > 12)) ? 0.43 : 0.0);
 }
 
 // Rows per workgroup of the resident plan: the rows of a workgroup share every column load, and the CU's vector-memory
@@ -350,16 +351,10 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     const bool fast_ok = p.qc.step >= 0x1p-40f && p.qc.step <= 0x1p40f && p.qc.Kf <= 1024.0f && !env_int("GPFQ_EXACT_DIVISIONS", 0);
     sp.inv_step = fast_ok ? 1.0f / p.qc.step : __builtin_nanf("");
     sp.msq_thr = 0.5f - (p.qc.Kf + 4.0f) * 0x1p-18f;
-    sp.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
+    // bit 0: pause before the first poll of an exchange (reducer_section: where 32 or more granules are awaited)
+    sp.spin_limit = 2u * (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21) +
+                    (env_int("GPFQ_COOP_POLL_DELAY", pl.RT * pl.C >= 32 ? 1 : 0) ? 1u : 0u);
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
-    // Exchange pacing (s_sleep 1 = 64 clocks each).  A poll that comes back without every granule costs a whole round
-    // trip AND sits in the way of the granules still travelling: the first poll waits for about the time the slowest
-    // member's store needs where 8 or more members are awaited (measured per column: 197-segment rows, 32 members x 4
-    // rows, 93 -> 72 us at 8 pauses; 181 segments, 16 members, 6.1 -> 5.7; 91 segments, 8 members x 4 rows, 2.84 ->
-    // 2.77; with 4 members any pause costs, 2-6 % over a whole layer).  The gap between two polls makes no difference
-    // that survives a whole-workload run (1 / 2 / 4 / 8 pauses: +- 1 %).
-    sp.poll_delay = env_int("GPFQ_COOP_POLL_DELAY", pl.C <= 4 ? 0 : 8);
-    sp.poll_gap = env_int("GPFQ_COOP_POLL_GAP", 1);
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     return sp;

@@ -94,12 +94,10 @@ struct SlabParams {
     int Ng, d, S, C, tiles, idx_bytes, vec;
     int pace;          // cooperative kernels: pauses (s_sleep 1 each) between the column requests issued in the exchange window; 0 = off
     int xcd_tiles;     // cooperative kernels: keep the members of a row tile on one XCD (needs tiles % 8 == 0)
-    int poll_delay;    // cooperative kernels: pauses (s_sleep 1 each) between publishing and the first poll
-    int poll_gap;      // ... and between two polls
     float step, Kf, lamb;
     float inv_step;    // fl(1 / step) for quant_msq_from_dot; NaN switches the division-free path off
     float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
-    unsigned spin_limit;
+    unsigned spin_limit;    // cooperative kernels: 2 * (polls before an exchange gives up) + (pause before the first poll ? 1 : 0)
     uint64_t seed, row_id0;
 };
 
@@ -156,13 +154,22 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         unsigned spins = 0;
         // lanes that gather nothing count as arrived; the compare mask goes straight into the scalar unit
         const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
-        for (int i = 0; i < p.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
+        // Pacing.  A poll that comes back without every granule costs a whole round trip AND sits in the way of the granules
+        // still travelling: where 32 or more granules are awaited (the host sets the flag) the first poll waits 8 pauses
+        // (512 clocks), about the time the slowest member's store needs.  Measured per column: 197-segment rows, 4 rows x
+        // 32 members, 93 -> 72 us; 181 segments, 4 x 16, 6.1 -> 5.7; 91 segments, 4 x 8, 2.84 -> 2.77; with 16 granules or
+        // fewer the pause costs (1 x 16: 1.52 -> 1.79, 2 x 8: 1.31 -> 1.47, 4 x 4: + 2-6 % over a layer); the gap between
+        // two polls makes no difference that survives a whole-workload run.
+        // (The flag rides in bit 0 of the spin limit, which this loop keeps in a scalar register anyway: a flag of its own,
+        // or a test on C, is one more live scalar, and the four-row kernels then restore spilt SGPRs on this very path:
+        // + 2.6 % on layer3.0.conv2.)
+        if (p.spin_limit & 1u) __builtin_amdgcn_s_sleep(8);
         if (!wide) {
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) | idle) == __builtin_amdgcn_read_exec()) break;
-                if (++spins > p.spin_limit) { timed_out = true; break; }
-                for (int i = 0; i < p.poll_gap; ++i) __builtin_amdgcn_s_sleep(1);
+                if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
             v = want ? __uint_as_float((unsigned)gv) : 0.0f;
         } else {
@@ -172,8 +179,8 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                 gw = __hip_atomic_load(src1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) &
                       __builtin_amdgcn_ballot_w64((unsigned)(gw >> 32) == epoch)) | idle) == __builtin_amdgcn_read_exec()) break;
-                if (++spins > p.spin_limit) { timed_out = true; break; }
-                for (int i = 0; i < p.poll_gap; ++i) __builtin_amdgcn_s_sleep(1);
+                if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
             v = want ? __uint_as_float((unsigned)gv) + __uint_as_float((unsigned)gw) : 0.0f;
         }
