@@ -344,3 +344,20 @@ def test_rows_longer_than_a_million_samples(qnn, oracle_mod, shape, plan):
     assert abs(float(r["quantize_error"]) - o["quantize_error"]) <= 1e-4 * o["quantize_error"]
     with pytest.raises(_lib.GpfqError):
         _lib.describe_plan(4, 4, 4_194_305)
+
+
+@pytest.mark.parametrize("shape", [(40, 300, 3000), (12, 120, 40000), (9, 200, 700)])
+def test_division_free_path_equals_the_division_path(qnn, monkeypatch, shape):
+    """MSQ layers find the index from one multiplication and run the reference's two divisions only near a rounding
+    boundary (gpfq_device.h quant_msq_from_dot); GPFQ_EXACT_DIVISIONS=1 runs the divisions on every step.  Same bits --
+    on the resident, the cooperative and the one-segment kernels, and on a layer with zero columns (zero dot products
+    always take the divisions)."""
+    N, d, m = shape
+    case = dict(name="fastdiv", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg=None, lamb=0.0, groups=1,
+                first_layer=False, zero_every=7, seed=33)
+    W, A, X = gi.make_inputs(case)
+    fast = _run_layer(qnn, case, W, A, X, 0)
+    monkeypatch.setenv("GPFQ_EXACT_DIVISIONS", "1")
+    exact = _run_layer(qnn, case, W, A, X, 0)
+    assert torch.equal(fast["idx"], exact["idx"]) and torch.equal(fast["U"], exact["U"])
+    assert torch.equal(fast["Q"].view(torch.int32), exact["Q"].view(torch.int32))
