@@ -568,6 +568,12 @@ int64_t gpfq_padded_m(int64_t m)
 
 size_t gpfq_scratch_bytes(void) { return kScratchBytes; }
 
+// waves per column of the norm kernel: 4, or 16 when the columns are few and long (every wave takes whole segments)
+static unsigned colnorm_threads(int64_t D, int S)
+{
+    return (D < 512 && S >= 64) ? 1024u : 256u;
+}
+
 static size_t ws_cols_bytes(int64_t d_g, int64_t m, int groups)
 {
     const size_t D = (size_t)d_g * (size_t)groups;
@@ -611,14 +617,21 @@ int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_
         return fail(GPFQ_ERR_ARG, "AT / XT must be 16-byte aligned");
     if (D == 0) return GPFQ_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(m_pad / 64), (unsigned)((D + 63) / 64), 2);
-    if (grid.y > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "too many columns");
-    hipLaunchKernelGGL(gpfq::gpfq_transpose_pad_kernel, grid, dim3(256), 0, st, A, lda, X, ldx, m, D, AT, XT, m_pad);
+    if (D <= 60 && lda == D && ldx == D && !env_int("GPFQ_NO_SMALL_TRANSPOSE", 0)) {      // (256 x 61 floats of LDS)
+        // few columns of contiguous matrices (first convs, EfficientNet's narrow 1x1 convs at 112 x 112): flat reads
+        const size_t shm = sizeof(float) * 256 * (size_t)((int)D | 1);
+        hipLaunchKernelGGL(gpfq::gpfq_transpose_pad_small_kernel, dim3((unsigned)(m_pad / 256), 2), dim3(256), shm, st, A, X, m,
+                           (int)D, AT, XT, m_pad);
+    } else {
+        dim3 grid((unsigned)(m_pad / 64), (unsigned)((D + 63) / 64), 2);
+        if (grid.y > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "too many columns");
+        hipLaunchKernelGGL(gpfq::gpfq_transpose_pad_kernel, grid, dim3(256), 0, st, A, lda, X, ldx, m, D, AT, XT, m_pad);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "transpose launch");
     const int S = (int)(m_pad / gpfq::kSeg);
-    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(256), sizeof(float) * (size_t)S, st, XT, m_pad,
-                       S, nrm2);
+    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(colnorm_threads(D, S)), sizeof(float) * (size_t)S, st,
+                       XT, m_pad, S, nrm2);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "colnorm launch");
     return GPFQ_OK;
@@ -712,7 +725,7 @@ int gpfq_column_norms_f32(const float* XT, int64_t D, int64_t m, int64_t m_pad, 
     if (D < 0 || m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "bad shape (m_pad must equal gpfq_padded_m(m))");
     if (D == 0) return GPFQ_OK;
     const int S = (int)(m_pad / gpfq::kSeg);
-    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(256), sizeof(float) * (size_t)S,
+    hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(colnorm_threads(D, S)), sizeof(float) * (size_t)S,
                        (hipStream_t)stream, XT, m_pad, S, nrm2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "colnorm launch");

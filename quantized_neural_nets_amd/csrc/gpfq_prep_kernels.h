@@ -43,16 +43,42 @@ __global__ void __launch_bounds__(256) gpfq_transpose_pad_kernel(const float* __
     }
 }
 
+// The same transpose for FEW columns (D <= 64) of contiguous matrices (lda == ldx == D): a 64-wide tile would leave most
+// of its lanes idle and read D * 4 bytes per row.  Here 256 rows of the matrix are one contiguous run of 256 * D floats:
+// read flat (fully coalesced), staged in LDS with an odd row stride, written as D runs of 256 floats.
+// grid = (m_pad / 256, 2): y = 0 the analog matrix, 1 the quantized one.
+__global__ void __launch_bounds__(256) gpfq_transpose_pad_small_kernel(const float* __restrict__ A, const float* __restrict__ X,
+                                                                       int64_t m, int D, float* __restrict__ AT,
+                                                                       float* __restrict__ XT, int64_t m_pad)
+{
+    extern __shared__ float tile[];                 // [256][D | 1]
+    const float* __restrict__ in = blockIdx.y ? X : A;
+    float* __restrict__ out = blockIdx.y ? XT : AT;
+    const int ldt = D | 1;
+    const int64_t k0 = (int64_t)blockIdx.x * 256;
+    const int64_t rows = (m - k0 < 256) ? (m - k0 > 0 ? m - k0 : 0) : 256;      // valid rows of this tile
+    const int64_t nflat = rows * D;
+    const float* __restrict__ src = in + k0 * D;
+    for (int f = threadIdx.x; f < 256 * D; f += 256) {
+        const int k = f / D, t = f - k * D;
+        tile[k * ldt + t] = (f < nflat) ? src[f] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = 0; t < D; ++t) out[(int64_t)t * m_pad + k0 + threadIdx.x] = tile[threadIdx.x * ldt + t];
+}
+
 // nrm2[2t] = (sqrt(cdot(x_t, x_t)))^2, canonical order, nrm2[2t + 1] = its reciprocal (0 for a zero column).
-// One 256-thread workgroup per column; dynamic LDS S floats.
-__global__ void __launch_bounds__(256) gpfq_colnorm_kernel(const float* __restrict__ XT, int64_t m_pad, int S,
+// One workgroup per column, 4 waves -- or 16 when there are few columns (a layer with 16 columns of 3.2 M samples would
+// otherwise keep 16 x 4 waves busy on the whole chip); dynamic LDS S floats.
+__global__ void __launch_bounds__(1024) gpfq_colnorm_kernel(const float* __restrict__ XT, int64_t m_pad, int S,
                                                            float* __restrict__ nrm2)
 {
     extern __shared__ float seg[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t col = (int64_t)gridDim.x - 1 - blockIdx.x;           // last column first (see gpfq_transpose_pad_kernel)
     const float* __restrict__ x = XT + col * m_pad + 4 * lane;
-    for (int s = wave; s < S; s += 4) {
+    const int nwaves = blockDim.x >> 6;
+    for (int s = wave; s < S; s += nwaves) {
         float xv[16];
         load16(xv, x + (int64_t)s * kSeg);
         float acc = 0.0f;
