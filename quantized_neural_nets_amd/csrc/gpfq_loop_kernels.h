@@ -117,11 +117,15 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 // own slots (nl <= 16 of them: a member has at most 12 segments), `stride` = max(16, C) lanes for the gathered
 // members (max(16, C/2) when RT * C > 64) -- so that both trees run all their levels without testing how many are needed: a taken branch costs
 // ~20 cycles on this chain, and adding +0.0f is exact (a partial sum is never -0.0f, see wave_tree16_zero_padded).
-// Returns whether the exchange timed out (wave-uniform; the same fact is left in the abort word of qs for the other waves).
-template <int RT, int MODE, bool FAST>
+// Returns whether the exchange timed out (wave-uniform).  Nothing else learns of it inside the launch: the status word is
+// raised, the outputs of the launch are void, and the sweep waves simply finish the loop on whatever q comes out (a
+// per-step abort test in every wave cost more than it could ever save).
+// ABORTWORD: the old protocol, kept for the four-row 12-wave variant only (no register left for the `gave_up` state):
+// the reducer leaves the fact in a word of qs and every wave tests it behind barrier 2 and leaves the loop.
+template <int RT, int MODE, bool FAST, bool ABORTWORD>
 __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int lane, int tile, int c, int C, int par,
-                                        int t, float n2cur, float in2cur, int row0, int64_t grow0, int seg_lo)
+                                        int t, float n2cur, float in2cur, int row0, int64_t grow0, int seg_lo, bool gave_up)
 {
     // this workgroup's block of the slot tree for all RT rows at once: lane = 16 * row + slot
     float v;
@@ -151,7 +155,9 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         const bool want = member < per_row && gr_ < RT;
         const unsigned long long* src = xb_ + (want ? (size_t)(wide ? 2 * member : member) * RT + gr_ : 0);
         unsigned long long gv = 0, gw = 0;
-        unsigned spins = 0;
+        // once an exchange of this launch has timed out (status raised, the host redoes the layer) the later ones give up
+        // at their first unanswered poll: the launch runs to its end on whatever q comes out, nobody needs an exit path
+        unsigned spins = gave_up ? p.spin_limit : 0u;
         // lanes that gather nothing count as arrived; the compare mask goes straight into the scalar unit
         const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
         // Pacing.  A poll that comes back without every granule costs a whole round trip AND sits in the way of the granules
@@ -195,7 +201,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
     int id;
     float q;
     // MSQ: index and value straight from the dot product (gpfq_device.h quant_msq_from_dot), the divisions only on the
-    // rare step whose quotient lies within 2^-19 of a rounding boundary in some lane; used first, checked second (see
+    // rare step whose quotient lies within (K + 4) * 2^-18 of a rounding boundary in some lane; used first, checked second (see
     // resident_body).  FAST is off in the four-row 12-wave variant: both paths do not fit the 56 registers it leaves
     // the compiler.
     bool redo = false;
@@ -243,12 +249,12 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
             }
         }
     }
-    if (lane == 0) {
-        qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
-        if (__builtin_expect(timed_out, 0)) {
-            atomicExch(p.status, 1);
-            p.status[1] = t; p.status[2] = tile; p.status[3] = c;
-        }
+    if constexpr (ABORTWORD) {
+        if (lane == 0) qs[par * (RT + 1) + RT] = timed_out ? 1.0f : 0.0f;
+    }
+    if (__builtin_expect(timed_out && !gave_up, 0) && lane == 0) {
+        atomicExch(p.status, 1);
+        p.status[1] = t; p.status[2] = tile; p.status[3] = c;
     }
     return timed_out;
 }
@@ -421,7 +427,9 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
 #define GPFQ_STAMP(i)
 #endif
     int t = 0;
-    bool dead = false;
+    constexpr bool ABORTWORD = (RT == 4 && DEPTH == 1);
+    bool gave_up = false;                           // reducer wave: an exchange of this launch has timed out
+    bool dead = false;                              // ABORTWORD only
     // Column requests in the exchange window (below) only when the reducer is a wave of its own: where wave 0 doubles as
     // the reducer (12 sweep waves) the window requests of the other eleven waves sit in front of its polls and the
     // exchange gets slower than the sweep phase gets faster (measured per column: 2.17 -> 2.4-2.5 us; with a dedicated
@@ -488,7 +496,12 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
         if (wave == rwave) {
             GPFQ_STAMP(4)
-            reducer_section<RT, MODE, (MODE == MODE_MSQ && !(RT == 4 && DEPTH == 1))>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, in2cur, row0, grow0, seg_lo);
+            if constexpr (ABORTWORD)
+                reducer_section<RT, MODE, false, true>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, in2cur, row0,
+                                                       grow0, seg_lo, false);
+            else
+                gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
+                                                                              n2cur, in2cur, row0, grow0, seg_lo, gave_up);
             GPFQ_STAMP(5)
         } else if (trickle && active) {
             // The exchange window: the sweep waves idle here for ~2 000 cycles while the reducer's granules travel.  Their
@@ -516,7 +529,9 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         }
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
-        if (qs[par * (RT + 1) + RT] != 0.0f) { dead = true; return false; }   // an exchange timed out: status word is set
+        if constexpr (ABORTWORD) {
+            if (qs[par * (RT + 1) + RT] != 0.0f) { dead = true; return false; }   // an exchange timed out: status word is set
+        }
         if (!more) return false;
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
@@ -767,7 +782,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         int id;
         float q;
         // MSQ: index and value straight from the dot product (gpfq_device.h quant_msq_from_dot), and the reference's two
-        // divisions only on the rare step whose quotient lies within 2^-19 of a rounding boundary.  The answer is used
+        // divisions only on the rare step whose quotient lies within (K + 4) * 2^-18 of a rounding boundary.  The answer is used
         // first and checked second: the check is a chain of its own, as long as the one to q, and a branch in front of
         // the readlanes would put it back on the critical path; behind them its condition has long been computed.  (The
         // same bits in every wave, so every wave takes the same side.)
