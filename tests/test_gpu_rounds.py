@@ -34,6 +34,8 @@ CASES = [
     ((21, 10, 803840), {}, "coop RT=2 C=64 waves=13 S=785 grid=256 rounds=3", "16-wave variant AND 128 granules, odd row count"),
     ((20, 10, 720384), {}, "coop RT=2 C=64 waves=11 S=704 grid=256 rounds=3", "128 granules at 64 members (VGG-16 conv1 rows)"),
     ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
+    ((12, 6, 1440768), {}, "coop RT=1 C=128 waves=11 S=1407 grid=256 rounds=6",
+     "128 members of one row (EfficientNet-B1's first conv at batch 1024): 64 lanes x 2 granules, two rows per round"),
 ]
 
 
