@@ -74,10 +74,11 @@ int env_int(const char* name, int dflt)
 int slab_max_waves(bool coop, int RT);
 int resident_max_rt(int waves);
 
-// wave bound of the cooperative kernel variant that takes NW sweep waves of RT rows (keep coop_kernel() in step)
-int coop_wave_bound(int RT, int NW)
+// wave bound of the cooperative kernel variant that takes NW sweep waves of RT rows split over C members (keep
+// coop_kernel() in step)
+int coop_wave_bound(int RT, int NW, int C)
 {
-    if (RT == 1) return 12;
+    if (RT == 1) return (NW <= 12 && C <= 128) ? 12 : 16;    // (16: the variant that gathers four members per lane)
     if (NW <= 8) return 8;
     return (NW <= 12 || RT != 2) ? 12 : 16;
 }
@@ -147,12 +148,13 @@ double resident_step_cost(int64_t Ng, int S, int cus)
 
 // What one column costs on the streaming plan (microseconds; measured on the ResNet-50 1x1 convolutions at batch
 // 1024, profiles/r02_v1_bench_r50_all_layers.txt: 4.7-5.5 TB/s of algorithmic bytes, 6.3 when the residual fits the
-// Infinity Cache and whole rows cover the chip).
+// Infinity Cache and whole rows cover the chip; EfficientNet-B1's 3137-segment rows 4.1-4.3).
 double stream_col_cost(int64_t Ng, int S, int cus)
 {
     const double bytes = 8.0 * (double)Ng * S * 4096.0 / 4.0;
     const bool cached = (double)Ng * S * 4096.0 <= 220e6 && Ng >= 4 * (int64_t)cus;
-    return bytes / (cached ? 6.3e6 : 5.0e6);
+    // (rows beyond 1024 segments: 4.1-4.3 TB/s measured -- few rows, the column split leaves a quarter of the CUs idle)
+    return bytes / (cached ? 6.3e6 : (S > 1024 ? 4.3e6 : 5.0e6));
 }
 
 // Cooperative configuration: cheapest modelled layer among the (RT, C) pairs.  A grid that is not co-resident as a
@@ -171,10 +173,12 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullpt
     for (int RT = 4; RT >= 1; RT >>= 1) {
         if (force_rt && RT != force_rt) continue;
         const int64_t tiles = (Ng + RT - 1) / RT;
-        for (int C = 128 / RT; C >= 2; C >>= 1) {                    // the reducer gathers RT * C <= 128 granules
+        // the reducer gathers RT * C <= 128 granules (two per lane) -- 256 in the one-row 16-wave variant (four per lane)
+        for (int C = (RT == 1 ? 256 : 128 / RT); C >= 2; C >>= 1) {
             if (force_c && C != force_c) continue;
             if (C > S || C > capacity) continue;
             const int NW = (S + C - 1) / C;
+            if (RT == 1 && (C > 128 || NW > 12) && (C < 4 || NW > 15)) continue;   // (that variant gathers in fours)
             if (NW > slab_max_waves(true, RT) || pow2_ceil_host(S) / C > 16) continue;
             const int64_t tiles_round = tiles * C <= capacity ? tiles : capacity / C;
             const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
@@ -183,7 +187,7 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullpt
             const int per_cu = (wgs + cus - 1) / cus;
             if ((per_cu * NW + 3) / 4 > 4) continue;
             // fewer workgroups than CUs simply leave CUs idle, which costs nothing per step
-            const int vmax = coop_wave_bound(RT, NW);                // wave bound of the variant launch_slab picks
+            const int vmax = coop_wave_bound(RT, NW, C);             // wave bound of the variant launch_slab picks
             const int launched = NW + (NW + 1 <= vmax ? 1 : 0);      // + the reducer wave when it fits
             const double cost = (double)rounds * slab_step_cost(RT, per_cu * launched, C, wgs);
             if (!found || cost < best - 1e-9) {
@@ -374,7 +378,7 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
         default: return gpfq::gpfq_coop_rt##RTV##_m0_w##MAXWV;                                                        \
         }                                                                                                             \
     }
-    GPFQ_PICK(1, 12) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(2, 16) GPFQ_PICK(4, 8)
+    GPFQ_PICK(1, 12) GPFQ_PICK(1, 16) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(2, 16) GPFQ_PICK(4, 8)
 #undef GPFQ_PICK
     if (RT == 4 && maxw == 12) {                    // (no stochastic variant: see GPFQ_DEFINE_COOP in gpfq_loop_kernels.h)
         switch (mode) {
@@ -390,7 +394,7 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
     const int RT = pl.RT;
-    const int maxw = coop_wave_bound(RT, pl.waves);
+    const int maxw = coop_wave_bound(RT, pl.waves, pl.C);
     SlabKernel kern = coop_kernel(RT, mode, maxw);
     if (!kern || pl.waves > maxw) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
     // one more wave for the reducer role when the variant's wave bound allows it
@@ -479,7 +483,7 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
 int slab_max_waves(bool coop, int RT)
 {
     if (!coop) return 16;
-    return RT == 2 ? 16 : 12;
+    return RT <= 2 ? 16 : 12;
 }
 
 int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scratch_bytes, hipStream_t st)

@@ -122,7 +122,9 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 // per-step abort test in every wave cost more than it could ever save).
 // ABORTWORD: the old protocol, kept for the four-row 12-wave variant only (no register left for the `gave_up` state):
 // the reducer leaves the fact in a word of qs and every wave tests it behind barrier 2 and leaves the loop.
-template <int RT, int MODE, bool FAST, bool ABORTWORD>
+// QUAD: the one-row 16-wave variant gathers FOUR members per lane (4j .. 4j+3: two levels of the tree over the members in
+// the lane), so that up to 256 members -- a whole chip for one row of up to 4096 segments -- fit the 64 lanes.
+template <int RT, int MODE, bool FAST, bool ABORTWORD, bool QUAD = false>
 __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int lane, int tile, int c, int C, int par,
                                         int t, float n2cur, float in2cur, int row0, int64_t grow0, int seg_lo, bool gave_up)
@@ -139,8 +141,9 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
     // Gather layout: lane = stride * row + member.  More than 64 granules (RT * C <= 128: long rows that run in rounds)
     // are gathered two members per lane, 2j and 2j+1 -- adjacent member blocks, the pair the first level of the tree
     // over the members adds anyway.
-    const bool wide = RT * C > 64;
-    const int per_row = wide ? C >> 1 : C;                    // lanes per row
+    static_assert(!QUAD || RT == 1, "four members per lane: one-row variant only");
+    const bool wide = !QUAD && RT * C > 64;
+    const int per_row = QUAD ? C >> 2 : (wide ? C >> 1 : C);  // lanes per row
     const int sh = per_row <= 16 ? 4 : (per_row <= 32 ? 5 : 6);   // log2 of the lane stride of a row in the gather
     const int gr_ = lane >> sh;              // row of this lane
     const int member = lane & ((1 << sh) - 1);
@@ -153,7 +156,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                                ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool want = member < per_row && gr_ < RT;
-        const unsigned long long* src = xb_ + (want ? (size_t)(wide ? 2 * member : member) * RT + gr_ : 0);
+        const unsigned long long* src = xb_ + (want ? (size_t)(QUAD ? 4 * member : (wide ? 2 * member : member)) * RT + gr_ : 0);
         unsigned long long gv = 0, gw = 0;
         // once an exchange of this launch has timed out (status raised, the host redoes the layer) the later ones give up
         // at their first unanswered poll: the launch runs to its end on whatever q comes out, nobody needs an exit path
@@ -170,7 +173,22 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         // or a test on C, is one more live scalar, and the four-row kernels then restore spilt SGPRs on this very path:
         // + 2.6 % on layer3.0.conv2.)
         if (p.spin_limit & 1u) __builtin_amdgcn_s_sleep(8);
-        if (!wide) {
+        if constexpr (QUAD) {
+            unsigned long long g[4];
+            for (;;) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[i] = __hip_atomic_load(src + (want ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long ok = ~0ull;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64((unsigned)(g[i] >> 32) == epoch);
+                if ((ok | idle) == __builtin_amdgcn_read_exec()) break;
+                if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            v = want ? (__uint_as_float((unsigned)g[0]) + __uint_as_float((unsigned)g[1])) +
+                           (__uint_as_float((unsigned)g[2]) + __uint_as_float((unsigned)g[3]))
+                     : 0.0f;
+        } else if (!wide) {
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) | idle) == __builtin_amdgcn_read_exec()) break;
@@ -325,7 +343,7 @@ __device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, b
 //     buffers alternate, one a buffer; column t+1 is requested into the registers sweep t has finished with -- it has
 //     the whole exchange to land -- and sweep t+1 waits for all of it (vmcnt(0)).
 // WB = first register of the window: x buffers, a buffers, then the RT residual rows.
-template <int RT, int MODE, int DEPTH, int WB>
+template <int RT, int MODE, int DEPTH, int WB, bool QUAD = false>
 __device__ __forceinline__ void coop_body(const SlabParams& p)
 {
     constexpr int NX = DEPTH == 2 ? 3 : 2, NA = DEPTH == 2 ? 2 : 1;
@@ -500,8 +518,8 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
                 reducer_section<RT, MODE, false, true>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, in2cur, row0,
                                                        grow0, seg_lo, false);
             else
-                gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
-                                                                              n2cur, in2cur, row0, grow0, seg_lo, gave_up);
+                gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
+                                                                                    n2cur, in2cur, row0, grow0, seg_lo, gave_up);
             GPFQ_STAMP(5)
         } else if (trickle && active) {
             // The exchange window: the sweep waves idle here for ~2 000 cycles while the reducer's granules travel.  Their
@@ -606,6 +624,16 @@ GPFQ_DEFINE_COOP(4, 0, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 1, 12, 1, 56, "v16
 // 128 - 48 - 32: two rows at 13..16 waves, for rows whose members would otherwise need a 13th sweep wave (P / C = 16 slots
 // per member and S / C just above 12: m = 803 840 is 785 segments, 12.3 per member at C = 64), one step of look-ahead.
 GPFQ_DEFINE_COOP_MODES(2, 16, 1, 48, "v127")
+// 128 - 48 - 16: ONE row at 13..16 waves, four gathered members per lane (up to 256 members: a whole chip for one row of
+// up to 4096 segments -- EfficientNet-B1's 112 x 112 maps at batch 1024 are 3137), one step of look-ahead.
+#define GPFQ_DEFINE_COOP_QUAD(MODE)                                                                               \
+    __global__ void __launch_bounds__(64 * 16) __attribute__((amdgpu_num_vgpr(64 / 2)))                            \
+    gpfq_coop_rt1_m##MODE##_w16(const SlabParams p)                                                               \
+    {                                                                                                             \
+        asm volatile("" ::: "v127");                                                                              \
+        coop_body<1, MODE, 1, 64, true>(p);                                                                       \
+    }
+GPFQ_DEFINE_COOP_QUAD(0) GPFQ_DEFINE_COOP_QUAD(1) GPFQ_DEFINE_COOP_QUAD(2) GPFQ_DEFINE_COOP_QUAD(3)
 
 // ------------------------------------------------------------------------------------------------
 // Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE

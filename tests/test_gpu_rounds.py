@@ -36,6 +36,10 @@ CASES = [
     ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
     ((12, 6, 1440768), {}, "coop RT=1 C=128 waves=11 S=1407 grid=256 rounds=6",
      "128 members of one row (EfficientNet-B1's first conv at batch 1024): 64 lanes x 2 granules, two rows per round"),
+    ((3, 4, 3212288), {}, "coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=3",
+     "one row on the whole chip (EfficientNet-B1's 112 x 112 maps): 256 members, four gathered per lane, 13 sweep waves"),
+    ((5, 4, 300000), {"GPFQ_COOP_RT": "1", "GPFQ_COOP_C": "256", "plan": "3"}, "coop RT=1 C=256 waves=2 S=293 grid=256 rounds=5",
+     "the same variant with two sweep waves per member and an idle upper half of the slot tree (293 of 512 slots)"),
 ]
 
 
@@ -43,12 +47,14 @@ CASES = [
 def test_rounds_equal_oracle_and_streaming(oracle_mod, monkeypatch, shape, env, plan_desc, why):
     from quantized_neural_nets_amd import _lib
     N, d, m = shape
+    env = dict(env)
+    plan = int(env.pop("plan", "0"))                 # 3: a configuration AUTO would not pick (it models streaming cheaper)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    assert _lib.describe_plan(N, d, m).startswith(plan_desc), _lib.describe_plan(N, d, m)
+    assert _lib.describe_plan(N, d, m, 1, plan).startswith(plan_desc), _lib.describe_plan(N, d, m, 1, plan)
     W, A, X = bw.synthetic_layer(N, d, m, 777 + N, first_layer=False)
     step = bw.layer_step(W)
-    r = _run(W, A, X, m, 0, step=step)
+    r = _run(W, A, X, m, plan, step=step)
     Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8)
     assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
     assert np.array_equal(r["Q"].cpu().numpy(), Q)

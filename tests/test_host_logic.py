@@ -76,7 +76,8 @@ def test_plan_selection(lib):
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=32 waves=7 S=197 grid=256 rounds=32")   # 128 granules
     assert lib.describe_plan(256, 64, 803840).startswith("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32")    # 16-wave variant
     assert lib.describe_plan(2048, 512, 13312).startswith("resident RT=1 waves=13")     # <= 16 segments: whole rows, no exchange
-    assert lib.describe_plan(16, 32, 3212288).startswith("stream")                      # 3137 segments: beyond 128 granules x 12
+    assert lib.describe_plan(16, 32, 3212288).startswith("coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=16")   # one row on the whole chip
+    assert lib.describe_plan(4, 8, 4194304).startswith("stream")                        # 4096 segments: beyond 256 members x 15
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
     # the fallback plan: whole rows per workgroup, never an exchange, whatever the shape
     for shape in ((64, 576, 93184), (8, 576, 93184), (512, 4608, 3072), (256, 2304, 803840)):
@@ -253,6 +254,8 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert bench.kernel_name("coop RT=2 C=4 waves=7 S=26 grid=256 d=1152", 1) == "gpfq_coop_rt2_m1_w8"
     assert bench.kernel_name("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32 d=64") == "gpfq_coop_rt2_m0_w16"
     assert bench.kernel_name("coop RT=4 C=32 waves=9 S=257 grid=256 rounds=2 d=147") == "gpfq_coop_rt4_m0_w12"
+    assert bench.kernel_name("coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=16 d=32", 1) == "gpfq_coop_rt1_m1_w16"
+    assert bench.kernel_name("coop RT=1 C=16 waves=6 S=91 grid=128 d=576") == "gpfq_coop_rt1_m0_w12"
     assert bench.plan_rounds("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32 d=64") == 32
     assert bench.plan_rounds("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == 1
     assert bench.l2_column_bytes("resident RT=2 waves=7 S=7 grid=(256,1) d=4608", 512, 4608, 7168) == 256 * 4608 * 8 * 7168

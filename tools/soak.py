@@ -44,7 +44,7 @@ def main():
             N, m = int(rng.integers(20, 200)), int(rng.integers(30000, 400000))
             rt = int(rng.choice([1, 2, 4]))
             os.environ["GPFQ_COOP_RT"] = str(rt)
-            os.environ["GPFQ_COOP_C"] = str(int(rng.choice([c for c in (8, 16, 32, 64, 128) if rt * c <= 128])))
+            os.environ["GPFQ_COOP_C"] = str(int(rng.choice([c for c in (8, 16, 32, 64, 128, 256) if rt * c <= (256 if rt == 1 else 128)])))
         elif fam == "stream":
             N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
         else:
