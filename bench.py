@@ -157,6 +157,8 @@ def kernel_name(desc, mode=0):
             return "gpfq_resident_rt%d_m%d_w1" % (rt, mode)
         return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
+        if "groups" in kv:                          # one row per group (depthwise convolutions)
+            return "gpfq_coop_rt1g_m%d_w12" % mode
         if rt == 1:
             return "gpfq_coop_rt1_m%d_w%d" % (mode, 16 if (waves > 12 or int(kv.get("C", "0")) > 128) else 12)
         return "gpfq_coop_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 16 if (rt == 2 and waves > 12) else 12)

@@ -50,6 +50,7 @@ struct Plan {
     int tiles;     // coop: row tiles
     int rounds;    // coop: launches the rows are spread over (every launch must be co-resident); 1 = all rows at once
     int tiles_round;   // coop: row tiles per launch
+    int grouped;   // coop: one row per group (depthwise convolutions), every row with its own columns
 };
 
 int device_cu_count()
@@ -194,8 +195,37 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullpt
                 found = true;
                 best = cost;
                 pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
-                pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round;
+                pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0;
             }
+        }
+    }
+    if (found && cost_out) *cost_out = best;
+    return found;
+}
+
+// Depthwise convolutions with long rows (groups == out channels, ONE row per group, 9 or 25 columns each, m up to 370 688
+// in EfficientNet-B1 at batch 1024): every group is a row of its own with its own columns, so the cooperative kernel's
+// one-row variant takes them as Ng = groups rows (GROUPED: per-row column base), in rounds of as many groups as fit the
+// chip.  The streaming plan gives each group one workgroup (17 GB/s of algorithmic bytes each: 96 groups of 362
+// segments 174 us per column); a round costs a cooperative step plus its launch spread over the few columns.
+bool choose_coop_grouped(int groups, int S, int cus, Plan* pl, double* cost_out)
+{
+    const int P = pow2_ceil_host(S);
+    double best = 1e30;
+    bool found = false;
+    for (int C = 128; C >= 2; C >>= 1) {
+        if (C > S || C > cus || P / C > 16) continue;
+        const int NW = (S + C - 1) / C;
+        if (NW > 12) continue;                                        // (the grouped variant is the 12-wave one-row kernel)
+        const int tiles_round = groups * C <= cus ? groups : cus / C;
+        const int rounds = (groups + tiles_round - 1) / tiles_round;
+        const int launched = NW + (NW + 1 <= 12 ? 1 : 0);
+        const double cost = rounds * (slab_step_cost(1, launched, C, tiles_round * C) + 1.3);
+        if (cost < best) {
+            found = true;
+            best = cost;
+            pl->kind = GPFQ_PLAN_COOP; pl->RT = 1; pl->C = C; pl->tiles = groups; pl->waves = NW; pl->S = S;
+            pl->rounds = rounds; pl->tiles_round = tiles_round; pl->grouped = 1;
         }
     }
     if (found && cost_out) *cost_out = best;
@@ -211,7 +241,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
     pl->kind = GPFQ_PLAN_STREAM;
     pl->S = S;
     pl->C = 1;
-    pl->rounds = 1; pl->tiles_round = 0;
+    pl->rounds = 1; pl->tiles_round = 0; pl->grouped = 0;
     pl->RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
     while (pl->RT > 1 && (size_t)2 * pl->RT * S * sizeof(float) > 48 * 1024) pl->RT >>= 1;   // the segment sums of RT rows live in LDS
     if (S > 1024 && pl->RT > 2) pl->RT = 2;               // (the four-row kernel has no 32 / 64-slots-per-lane tree)
@@ -252,7 +282,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
 int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, Plan* out)
 {
     Plan pl;
-    pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0;
+    pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0; pl.grouped = 0;
     if (m_pad / gpfq::kSeg > 4096) return fail(GPFQ_ERR_UNSUPPORTED, "m > 4194304 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
     if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_STREAM_ROWS) return fail(GPFQ_ERR_ARG, "unknown plan id");
@@ -280,6 +310,16 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
         }
         *out = pl;
         return GPFQ_OK;
+    }
+    if (groups > 1 && Ng == 1 && pl.S > kMaxResidentSegments && have_scratch && requested != GPFQ_PLAN_STREAM &&
+        !env_int("GPFQ_COOP_DISABLE", 0)) {
+        Plan gp = pl;
+        double gcost = 0.0;
+        const double stream_cost = 8.0 * pl.S * 1024.0 / 0.017e6 * ((groups + cus - 1) / cus);
+        if (choose_coop_grouped(groups, pl.S, cus, &gp, &gcost) && (requested == GPFQ_PLAN_COOP || gcost < 0.9 * stream_cost)) {
+            *out = gp;
+            return GPFQ_OK;
+        }
     }
     if (requested == GPFQ_PLAN_COOP || (requested == GPFQ_PLAN_AUTO && !env_int("GPFQ_COOP_DISABLE", 0))) {
         double ccost = 0.0;
@@ -391,11 +431,22 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
     return nullptr;
 }
 
+// one row per group, 12 waves (gpfq_loop_kernels.h GPFQ_DEFINE_COOP_GROUPED)
+SlabKernel coop_kernel_grouped(int mode)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return gpfq::gpfq_coop_rt1g_m1_w12;
+    case gpfq::MODE_HARD: return gpfq::gpfq_coop_rt1g_m2_w12;
+    case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_coop_rt1g_m3_w12;
+    default: return gpfq::gpfq_coop_rt1g_m0_w12;
+    }
+}
+
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
     const int RT = pl.RT;
-    const int maxw = coop_wave_bound(RT, pl.waves, pl.C);
-    SlabKernel kern = coop_kernel(RT, mode, maxw);
+    const int maxw = pl.grouped ? 12 : coop_wave_bound(RT, pl.waves, pl.C);
+    SlabKernel kern = pl.grouped ? coop_kernel_grouped(mode) : coop_kernel(RT, mode, maxw);
     if (!kern || pl.waves > maxw) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
     // one more wave for the reducer role when the variant's wave bound allows it
     const int nwaves = pl.waves + ((pl.waves + 1 <= maxw && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
@@ -503,6 +554,28 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     if (groups > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "groups > 65535");
     p.S = pl.S;
     const bool vec = ((p.ldu & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.U) & 15) == 0);
+    if (pl.kind == GPFQ_PLAN_COOP && pl.grouped) {
+        // one row per group: the kernel sees Ng = (groups of this round) rows of ONE group, each row with its own
+        // columns (GROUPED); a round is a block of groups
+        rc = GPFQ_OK;
+        for (int64_t g0 = 0; g0 < groups && rc == GPFQ_OK; g0 += pl.tiles_round) {
+            gpfq::LoopParams q = p;
+            Plan pr = pl;
+            q.Ng = (groups - g0 < pl.tiles_round) ? groups - g0 : pl.tiles_round;
+            pr.tiles = (int)q.Ng;
+            q.W = p.W + g0 * p.ldw; q.Q = p.Q + g0 * p.ldq; q.U = p.U + g0 * p.ldu;
+            if (p.idx) q.idx = static_cast<char*>(p.idx) + g0 * p.ldi * p.idx_bytes;
+            if (p.usq) q.usq = p.usq + g0 * pl.S;
+            q.AT = p.AT + g0 * p.d * p.m_pad; q.XT = p.XT + g0 * p.d * p.m_pad; q.nrm2 = p.nrm2 + 2 * g0 * p.d;
+            q.row_id0 = p.row_id0 + (uint64_t)g0;
+            rc = launch_slab(pr, q, 1, vec, scratch, st);
+            if (rc == GPFQ_ERR_UNSUPPORTED && g0 > 0) return fail(GPFQ_ERR_HIP, "internal: a later round of a cooperative layer did not fit");
+        }
+        if (rc == GPFQ_OK) g_used_exchange = 1;
+        if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
+        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, &pl);   // does not fit: stream instead
+        if (rc) return rc;
+    }
     if (pl.kind == GPFQ_PLAN_COOP) {
         if (pl.rounds <= 1) {
             rc = launch_slab(pl, p, groups, vec, scratch, st);
@@ -779,7 +852,10 @@ int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, 
     int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, &pl);
     if (rc) return rc;
     if (buf && buf_bytes) {
-        if (pl.kind == GPFQ_PLAN_COOP && pl.rounds > 1)
+        if (pl.kind == GPFQ_PLAN_COOP && pl.grouped)
+            snprintf(buf, buf_bytes, "coop RT=1 C=%d waves=%d S=%d grid=%d rounds=%d groups=%d d=%lld", pl.C, pl.waves, pl.S,
+                     pl.tiles_round * pl.C, pl.rounds, groups, (long long)d_g);
+        else if (pl.kind == GPFQ_PLAN_COOP && pl.rounds > 1)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d rounds=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
                      pl.tiles_round * pl.C, pl.rounds, (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_COOP)

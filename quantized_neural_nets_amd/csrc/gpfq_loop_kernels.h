@@ -343,7 +343,10 @@ __device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, b
 //     buffers alternate, one a buffer; column t+1 is requested into the registers sweep t has finished with -- it has
 //     the whole exchange to land -- and sweep t+1 waits for all of it (vmcnt(0)).
 // WB = first register of the window: x buffers, a buffers, then the RT residual rows.
-template <int RT, int MODE, int DEPTH, int WB, bool QUAD = false>
+// GROUPED: every row is a group of its own (depthwise convolutions: groups == out channels, one row per group) with its
+// OWN d columns: row r reads columns [r * d, (r + 1) * d) and their norms.  The host presents such a layer as Ng = groups
+// rows of one group (run_loop); everything else -- exchange, rounds, Philox keys by global row -- is the plain kernel.
+template <int RT, int MODE, int DEPTH, int WB, bool QUAD = false, bool GROUPED = false>
 __device__ __forceinline__ void coop_body(const SlabParams& p)
 {
     constexpr int NX = DEPTH == 2 ? 3 : 2, NA = DEPTH == 2 ? 2 : 1;
@@ -383,10 +386,12 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
 
     const int row0 = tile * RT;
     const int64_t grow0 = row0;                     // groups == 1
-    const float* xload = uniform_ptr(p.XT + (int64_t)myseg * kSeg);      // wave-uniform column pointers
-    const float* aload = uniform_ptr(p.AT + (int64_t)myseg * kSeg);
+    static_assert(!GROUPED || RT == 1, "one row per group");
+    const int64_t gcol = GROUPED ? (int64_t)tile * p.d : 0;             // first column of this row's group
+    const float* xload = uniform_ptr(p.XT + gcol * p.m_pad + (int64_t)myseg * kSeg);      // wave-uniform column pointers
+    const float* aload = uniform_ptr(p.AT + gcol * p.m_pad + (int64_t)myseg * kSeg);
     const unsigned lane_off = 16u * (unsigned)lane;
-    const kfloat* nrm = as_scalar(p.nrm2);
+    const kfloat* nrm = as_scalar(p.nrm2 + 2 * gcol);
 
     const kfloat* wrow[RT];
     float qprev[RT], wcur[RT];
@@ -634,6 +639,15 @@ GPFQ_DEFINE_COOP_MODES(2, 16, 1, 48, "v127")
         coop_body<1, MODE, 1, 64, true>(p);                                                                       \
     }
 GPFQ_DEFINE_COOP_QUAD(0) GPFQ_DEFINE_COOP_QUAD(1) GPFQ_DEFINE_COOP_QUAD(2) GPFQ_DEFINE_COOP_QUAD(3)
+// one row per group (depthwise convolutions with long rows), 12 waves: the one-row variant with per-row columns
+#define GPFQ_DEFINE_COOP_GROUPED(MODE)                                                                            \
+    __global__ void __launch_bounds__(64 * 12) __attribute__((amdgpu_num_vgpr(72 / 2)))                            \
+    gpfq_coop_rt1g_m##MODE##_w12(const SlabParams p)                                                              \
+    {                                                                                                             \
+        asm volatile("" ::: "v167");                                                                              \
+        coop_body<1, MODE, 2, 72, false, true>(p);                                                                \
+    }
+GPFQ_DEFINE_COOP_GROUPED(0) GPFQ_DEFINE_COOP_GROUPED(1) GPFQ_DEFINE_COOP_GROUPED(2) GPFQ_DEFINE_COOP_GROUPED(3)
 
 // ------------------------------------------------------------------------------------------------
 // Resident plan (whole rows in one workgroup, S <= 16 segments, one wave per segment): NO reducer role and ONE

@@ -21,7 +21,7 @@ CASES = [
     ("resnet18_fc_b256", 1000, 64, 256, 1, 4, None, 0.1, "resident"),
     ("vgg16_conv1_2_b512", 16, 40, bw.conv_m(512, 224, 3, 1), 1, 4, None, 0.1, "coop RT=2 C=64"),   # m = 720 384: 704 segments, two rounds
     ("vgg16_fc6_b512", 128, 256, 512, 1, 4, None, 0.1, "resident"),
-    ("effnet_b1_depthwise_b1024", 8, 9, bw.conv_m(1024, 112, 3, 1), 8, 2, "L1", 0.1, "stream"),   # m = 370 688, N_g = 1
+    ("effnet_b1_depthwise_b1024", 8, 9, bw.conv_m(1024, 112, 3, 1), 8, 2, "L1", 0.1, "coop RT=1 C=32 waves=12 S=362 grid=256 rounds=1 groups=8"),   # m = 370 688, N_g = 1
     ("effnet_b1_depthwise5_b1024", 12, 25, bw.conv_m(1024, 14, 5, 2), 12, 2, "L1", 0.1, "resident"),
     ("effnet_b1_se_reduce_b1024", 24, 96, 1024, 1, 2, "L1", 0.1, "resident"),         # 1x1 conv on a 1x1 map: m = B
     ("effnet_b1_project_b1024", 40, 60, bw.conv_m(1024, 28, 1, 0), 1, 2, "L1", 0.1, "coop RT=4 C=32"),    # m = 201 728: two rounds
@@ -49,7 +49,7 @@ def test_config_layer_shape_bit_exact(oracle_mod, case):
     assert abs(float(r["relative_quantize_error"]) - o["relative_quantize_error"]) <= 2e-4 * o["relative_quantize_error"]
     if reg == "L1":                                   # sparse GPFQ really produces zeros
         assert float((r["idx"] == 0).float().mean()) > 0.2
-    if "rounds=" in _lib.describe_plan(N, d, m, groups):   # the streaming family at the same shape (what these rows ran on before rounds)
+    if "rounds=" in _lib.describe_plan(N, d, m, groups):   # the streaming family at the same shape (what these rows ran on before)
         st = SA._quantize_layer_ex(torch.from_numpy(W).to(DEV), torch.from_numpy(A).to(DEV), torch.from_numpy(X).to(DEV), m,
                                    1.16 / K, K, 1.0, reg, lamb, groups, False, torch.device(DEV), plan=_lib.PLAN_STREAM)
         assert torch.equal(st["idx"], r["idx"]) and torch.equal(st["U"], r["U"])

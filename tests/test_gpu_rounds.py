@@ -112,3 +112,34 @@ def test_rounds_stop_after_a_timeout_and_the_layer_is_redone(monkeypatch):
     torch.cuda.synchronize()
     assert r["timeouts"], "the forced timeout was not reported"
     assert torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"])
+
+
+@pytest.mark.parametrize("mode", ["msq", "soft", "stochastic"])
+def test_depthwise_long_rows_one_row_per_group(oracle_mod, mode):
+    """Depthwise convolutions (groups == out channels, one row per group, every group with its own 9 columns) with long
+    rows: the cooperative kernel's grouped variant in rounds of as many groups as fit the chip -- EfficientNet-B1's
+    features.2.0.block.1.0 at batch 1024 is 96 groups of 370 688 samples.  Against the oracle and the streaming plan,
+    bit for bit; the stochastic quantizer's keys are the global rows (= groups)."""
+    from quantized_neural_nets_amd import StepAlgorithm as SA, _lib
+    omode = {"msq": oracle_mod.MODE_MSQ, "soft": oracle_mod.MODE_SOFT, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
+    for (G, dg, m, want) in ((19, 9, 370688, "coop RT=1 C=32 waves=12 S=362 grid=256 rounds=3 groups=19"),
+                             (70, 5, 30000, "coop RT=1 C=4 waves=8 S=30 grid=256 rounds=2 groups=70")):
+        assert _lib.describe_plan(G, dg, m, G).startswith(want), _lib.describe_plan(G, dg, m, G)
+        W, A, X = bw.synthetic_layer(G, G * dg, m, 31 + G, first_layer=False)
+        W = W[:, :dg].contiguous()
+        reg = {"soft": "L1"}.get(mode)
+        K = 2
+
+        def run(plan):
+            r = SA._quantize_layer_ex(W.to(DEV), A.to(DEV), X.to(DEV), m, 1.16 / K, K, 1, reg, 0.05, G, mode == "stochastic",
+                                      torch.device(DEV), plan=plan, seed=99, compute_errors=False)
+            torch.cuda.synchronize()
+            assert r["timeouts"] == []
+            return r
+        r = run(0)
+        o = oracle_mod.quantize_layer(W.numpy(), A.numpy(), X.numpy(), 1.16 / K, K, 1.0, reg, 0.05, G,
+                                      **({"stochastic": True, "seed": 99} if mode == "stochastic" else {}))
+        assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
+        assert np.array_equal(r["U"].cpu().numpy(), o["U"])
+        st = run(1)
+        assert torch.equal(st["idx"], r["idx"]) and torch.equal(st["U"], r["U"]) and torch.equal(st["usq_seg"], r["usq_seg"])

@@ -70,7 +70,9 @@ def test_plan_selection(lib):
     assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=16 waves=6")        # an 8-GPU shard of 64 rows
     assert lib.describe_plan(32, 2304, 26624).startswith("coop RT=1 C=8 waves=4")       # an 8-GPU shard of 256 rows
     assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=4 C=2 waves=7")      # long rows, more rows than CUs
-    assert lib.describe_plan(64, 9, 30000, 64).startswith("stream")                     # grouped: never cooperative
+    assert lib.describe_plan(64, 9, 30000, 64).startswith("coop RT=1 C=4 waves=8 S=30 grid=256 rounds=1 groups=64")   # depthwise, long rows: one row per group
+    assert lib.describe_plan(96, 9, 370688, 96).startswith("coop RT=1 C=32 waves=12 S=362 grid=256 rounds=12 groups=96")
+    assert lib.describe_plan(64, 9, 30000, 32).startswith("stream")                     # two rows per group: not the depthwise case
     # long rows, more of them than the chip holds: cooperative in rounds (one co-resident launch per block of rows)
     assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=4 C=8 waves=7 S=50 grid=256 rounds=16")
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=32 waves=7 S=197 grid=256 rounds=32")   # 128 granules
@@ -256,6 +258,7 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert bench.kernel_name("coop RT=4 C=32 waves=9 S=257 grid=256 rounds=2 d=147") == "gpfq_coop_rt4_m0_w12"
     assert bench.kernel_name("coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=16 d=32", 1) == "gpfq_coop_rt1_m1_w16"
     assert bench.kernel_name("coop RT=1 C=16 waves=6 S=91 grid=128 d=576") == "gpfq_coop_rt1_m0_w12"
+    assert bench.kernel_name("coop RT=1 C=32 waves=12 S=362 grid=256 rounds=12 groups=96 d=9", 1) == "gpfq_coop_rt1g_m1_w12"
     assert bench.plan_rounds("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32 d=64") == 32
     assert bench.plan_rounds("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == 1
     assert bench.l2_column_bytes("resident RT=2 waves=7 S=7 grid=(256,1) d=4608", 512, 4608, 7168) == 256 * 4608 * 8 * 7168
