@@ -26,7 +26,7 @@ def main():
     t0 = time.time()
     bad = 0
     for ci in range(ncases):
-        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped"])
+        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise"])
         groups = 1
         if fam == "wave":                           # one-segment rows: the resident kernel's one-wave variant, 1 / 2 / 4 rows per wave
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
@@ -47,10 +47,13 @@ def main():
             os.environ["GPFQ_COOP_C"] = str(int(rng.choice([c for c in (8, 16, 32, 64, 128, 256) if rt * c <= (256 if rt == 1 else 128)])))
         elif fam == "stream":
             N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
+        elif fam == "depthwise":                    # one long row per group: the cooperative one-row kernel's grouped variant
+            groups = int(rng.integers(2, 60))
+            N, m = groups, int(rng.integers(17000, 200000))
         else:
             groups = int(rng.choice([2, 3, 4]))
             N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
-        d = int(rng.integers(1, 7 if fam == "rounds" else 12 if fam == "coop_rows" else 40))
+        d = int(rng.integers(1, 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam == "coop_rows" else 40))
         bits = int(rng.choice([2, 3, 4]))
         reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
         plan = 1 if fam == "stream" else 0
@@ -67,7 +70,7 @@ def main():
         os.environ.pop("GPFQ_RESIDENT_RT", None)
         o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
         full = _lib.describe_plan(N, d, m, groups, plan)
-        desc = full.split()[0] + ("+rounds" if "rounds=" in full else "")
+        desc = full.split()[0] + ("+groups" if "groups=" in full else "+rounds" if "rounds=" in full else "")
         kinds[desc] = kinds.get(desc, 0) + 1
         os.environ.pop("GPFQ_COOP_RT", None)
         os.environ.pop("GPFQ_COOP_C", None)
