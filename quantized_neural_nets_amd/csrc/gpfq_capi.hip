@@ -503,6 +503,23 @@ SlabKernel resident_kernel(int RT, int mode, int maxw)
     return nullptr;
 }
 
+// one-segment rows whose samples fill one or two quarters of the segment
+SlabKernel resident_kernel_partial(int RT, int mode, int nq)
+{
+#define GPFQ_PICKQ(RTV, NQV)                                                                                          \
+    if (RT == RTV && nq == NQV) {                                                                                     \
+        switch (mode) {                                                                                               \
+        case gpfq::MODE_SOFT: return gpfq::gpfq_resident_rt##RTV##_m1_w1q##NQV;                                       \
+        case gpfq::MODE_HARD: return gpfq::gpfq_resident_rt##RTV##_m2_w1q##NQV;                                       \
+        case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_resident_rt##RTV##_m3_w1q##NQV;                                 \
+        default: return gpfq::gpfq_resident_rt##RTV##_m0_w1q##NQV;                                                    \
+        }                                                                                                             \
+    }
+    GPFQ_PICKQ(1, 1) GPFQ_PICKQ(2, 1) GPFQ_PICKQ(4, 1) GPFQ_PICKQ(1, 2) GPFQ_PICKQ(2, 2) GPFQ_PICKQ(4, 2)
+#undef GPFQ_PICKQ
+    return nullptr;
+}
+
 // most rows per workgroup the register budget of a wave bound leaves room for (the window takes 80 of it)
 int resident_max_rt(int waves) { return waves <= 8 ? 4 : (waves <= 12 ? 2 : 1); }
 
@@ -510,7 +527,9 @@ int launch_resident(const Plan& pl, const gpfq::SlabParams& sp, int mode, int gr
 {
     if (pl.waves != pl.S || pl.S > 16) return fail(GPFQ_ERR_UNSUPPORTED, "internal: resident plan needs one wave per segment");
     const int maxw = pl.S == 1 ? 1 : (pl.waves <= 8 ? 8 : (pl.waves <= 12 ? 12 : 16));     // 1: the one-segment variant
-    SlabKernel k = resident_kernel(pl.RT, mode, maxw);
+    // one-segment rows of m <= 256 / 512 samples: the variants that load and sweep one / two quarters of the segment
+    const int nq = (pl.S == 1 && !env_int("GPFQ_FULL_SEGMENT", 0)) ? (sp.m <= 256 ? 1 : (sp.m <= 512 ? 2 : 4)) : 4;
+    SlabKernel k = nq < 4 ? resident_kernel_partial(pl.RT, mode, nq) : resident_kernel(pl.RT, mode, maxw);
     if (!k) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no resident kernel for this (rows, waves) pair");
     const size_t shm = sizeof(float) * 2 * (size_t)pl.RT * (size_t)pl.S;
     dim3 grid((unsigned)((sp.Ng + pl.RT - 1) / pl.RT), (unsigned)groups, 1);

@@ -421,19 +421,22 @@ __device__ __forceinline__ void load16(float (&dst)[16], const float* __restrict
 // window needs (loads -> wait -> sweep); everything the compiler sees (residual rows, sums) is ordinary data flow.
 //
 // B = first register of a buffer, Q = quarter (4 of the 16 elements: one 16-byte load per lane).
-template <int B, int Q>
+// NQ = quarters of the 1024-element segment that hold data (one-segment rows of m <= 256 / 512 samples: 1 / 2): the
+// others are zero padding -- never loaded, never swept (x = a = 0 leaves u = 0 and the dot product untouched, exactly)
+template <int B, int Q, int NQ = 4>
 __device__ __forceinline__ void win_load4(const float* base, unsigned lane_off)
 {
-    asm volatile("global_load_dwordx4 v[%c2+%c3:%c2+%c3+3], %0, %1 offset:%c4"
-                 :: "v"(lane_off), "s"(base), "n"(B), "n"(4 * Q), "n"(1024 * Q));
+    if constexpr (Q < NQ)
+        asm volatile("global_load_dwordx4 v[%c2+%c3:%c2+%c3+3], %0, %1 offset:%c4"
+                     :: "v"(lane_off), "s"(base), "n"(B), "n"(4 * Q), "n"(1024 * Q));
 }
-template <int B>
+template <int B, int NQ = 4>
 __device__ __forceinline__ void win_load16(const float* base, unsigned lane_off)
 {
-    win_load4<B, 0>(base, lane_off);
-    win_load4<B, 1>(base, lane_off);
-    win_load4<B, 2>(base, lane_off);
-    win_load4<B, 3>(base, lane_off);
+    win_load4<B, 0, NQ>(base, lane_off);
+    win_load4<B, 1, NQ>(base, lane_off);
+    win_load4<B, 2, NQ>(base, lane_off);
+    win_load4<B, 3, NQ>(base, lane_off);
 }
 template <int B>
 __device__ __forceinline__ void win_zero16()
@@ -460,7 +463,7 @@ __device__ __forceinline__ void win_wait()
 // of 80, which matters because a wave issues one vector instruction per 4 cycles however idle its SIMD is.
 // {q, w} travel as ONE register pair; op_sel broadcasts its low half (q) or its high half (w) to both lanes of the pack.
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int U, int XP, int A, int X>
+template <int U, int XP, int A, int X, int NQ = 4>
 __device__ __forceinline__ float win_sweep16(float q, float w)
 {
     float acc;
@@ -473,6 +476,13 @@ __device__ __forceinline__ float win_sweep16(float q, float w)
     "v_pk_add_f32 v[%c4+" #e ":%c4+" #e1 "], v[%c4+" #e ":%c4+" #e1 "], %2\n\t"                           \
     "v_fmac_f32 %0, v[%c4+" #e "], v[%c7+" #e "]\n\t"                                                   \
     "v_fmac_f32 %0, v[%c4+" #e1 "], v[%c7+" #e1 "]\n\t"
+    if constexpr (NQ == 1)
+        asm volatile("v_mov_b32 %0, 0\n\t" GPFQ_S(0, 1) GPFQ_S(2, 3) "s_nop 1"
+                     : "=&v"(acc), "=&v"(t0), "=&v"(t1) : "v"(qw), "n"(U), "n"(XP), "n"(A), "n"(X));
+    else if constexpr (NQ == 2)
+        asm volatile("v_mov_b32 %0, 0\n\t" GPFQ_S(0, 1) GPFQ_S(2, 3) GPFQ_S(4, 5) GPFQ_S(6, 7) "s_nop 1"
+                     : "=&v"(acc), "=&v"(t0), "=&v"(t1) : "v"(qw), "n"(U), "n"(XP), "n"(A), "n"(X));
+    else
     asm volatile("v_mov_b32 %0, 0\n\t"
                  GPFQ_S(0, 1) GPFQ_S(2, 3) GPFQ_S(4, 5) GPFQ_S(6, 7) GPFQ_S(8, 9) GPFQ_S(10, 11) GPFQ_S(12, 13) GPFQ_S(14, 15)
                  "s_nop 1"
@@ -492,32 +502,21 @@ __device__ __forceinline__ float win_sweep16(float q, float w)
     "v_pk_add_f32 v[%c5+" #u0 ":%c5+" #u1 "], v[%c5+" #u0 ":%c5+" #u1 "], %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"           \
     "v_pk_add_f32 v[%c5+" #u0 ":%c5+" #u1 "], v[%c5+" #u0 ":%c5+" #u1 "], %2\n\t"                                     \
     "v_pk_fma_f32 %0, v[%c5+" #u0 ":%c5+" #u1 "], v[%c8+" #kb ":%c8+" #kb1 "], %0 op_sel:[0," #sel ",0] op_sel_hi:[1," #sel ",1]\n\t"
-template <int UP, int XP, int A, int X>
+template <int UP, int XP, int A, int X, int NQ = 4>
 __device__ __forceinline__ v2f win_sweep16_pair(float q0, float q1, float w0, float w1)
 {
     v2f acc = {0.0f, 0.0f};
     v2f t0, t1;
     const v2f qq = {q0, q1}, ww = {w0, w1};
-    asm volatile(
-    GPFQ_SP(0, 1, 0, 1, 0)
-    GPFQ_SP(2, 3, 0, 1, 1)
-    GPFQ_SP(4, 5, 2, 3, 0)
-    GPFQ_SP(6, 7, 2, 3, 1)
-    GPFQ_SP(8, 9, 4, 5, 0)
-    GPFQ_SP(10, 11, 4, 5, 1)
-    GPFQ_SP(12, 13, 6, 7, 0)
-    GPFQ_SP(14, 15, 6, 7, 1)
-    GPFQ_SP(16, 17, 8, 9, 0)
-    GPFQ_SP(18, 19, 8, 9, 1)
-    GPFQ_SP(20, 21, 10, 11, 0)
-    GPFQ_SP(22, 23, 10, 11, 1)
-    GPFQ_SP(24, 25, 12, 13, 0)
-    GPFQ_SP(26, 27, 12, 13, 1)
-    GPFQ_SP(28, 29, 14, 15, 0)
-    GPFQ_SP(30, 31, 14, 15, 1)
-                 "s_nop 1"
-                 : "+v"(acc), "=&v"(t0), "=&v"(t1)
-                 : "v"(qq), "v"(ww), "n"(UP), "n"(XP), "n"(A), "n"(X));
+    if constexpr (NQ == 1)
+        asm volatile(GPFQ_SP(0, 1, 0, 1, 0) GPFQ_SP(2, 3, 0, 1, 1) GPFQ_SP(4, 5, 2, 3, 0) GPFQ_SP(6, 7, 2, 3, 1) "s_nop 1"
+                     : "+v"(acc), "=&v"(t0), "=&v"(t1) : "v"(qq), "v"(ww), "n"(UP), "n"(XP), "n"(A), "n"(X));
+    else if constexpr (NQ == 2)
+        asm volatile(GPFQ_SP(0, 1, 0, 1, 0) GPFQ_SP(2, 3, 0, 1, 1) GPFQ_SP(4, 5, 2, 3, 0) GPFQ_SP(6, 7, 2, 3, 1) GPFQ_SP(8, 9, 4, 5, 0) GPFQ_SP(10, 11, 4, 5, 1) GPFQ_SP(12, 13, 6, 7, 0) GPFQ_SP(14, 15, 6, 7, 1) "s_nop 1"
+                     : "+v"(acc), "=&v"(t0), "=&v"(t1) : "v"(qq), "v"(ww), "n"(UP), "n"(XP), "n"(A), "n"(X));
+    else
+        asm volatile(GPFQ_SP(0, 1, 0, 1, 0) GPFQ_SP(2, 3, 0, 1, 1) GPFQ_SP(4, 5, 2, 3, 0) GPFQ_SP(6, 7, 2, 3, 1) GPFQ_SP(8, 9, 4, 5, 0) GPFQ_SP(10, 11, 4, 5, 1) GPFQ_SP(12, 13, 6, 7, 0) GPFQ_SP(14, 15, 6, 7, 1) GPFQ_SP(16, 17, 8, 9, 0) GPFQ_SP(18, 19, 8, 9, 1) GPFQ_SP(20, 21, 10, 11, 0) GPFQ_SP(22, 23, 10, 11, 1) GPFQ_SP(24, 25, 12, 13, 0) GPFQ_SP(26, 27, 12, 13, 1) GPFQ_SP(28, 29, 14, 15, 0) GPFQ_SP(30, 31, 14, 15, 1) "s_nop 1"
+                     : "+v"(acc), "=&v"(t0), "=&v"(t1) : "v"(qq), "v"(ww), "n"(UP), "n"(XP), "n"(A), "n"(X));
     return acc;
 }
 #undef GPFQ_SP

@@ -672,9 +672,12 @@ GPFQ_DEFINE_COOP_GROUPED(0) GPFQ_DEFINE_COOP_GROUPED(1) GPFQ_DEFINE_COOP_GROUPED
 // three x buffers, two a buffers, then the RT residual rows.
 // ONE = rows of a single segment (m <= 1024: every fully connected layer, 1x1 convs on 1x1 maps): the workgroup is one
 // wave, the lane tree's total IS the dot product -- no LDS word, no barrier, no slot tree.
-template <int RT, int MODE, int WB, bool ONE = false>
+// NQ (ONE only) = quarters of the segment that hold samples: m <= 256 -> 1, m <= 512 -> 2 (VGG-16's fully connected layers
+// at batch 512, AlexNet's at 32): the zero padding is neither loaded nor swept.
+template <int RT, int MODE, int WB, bool ONE = false, int NQ = 4>
 __device__ __forceinline__ void resident_body(const SlabParams& p)
 {
+    static_assert(NQ == 4 || ONE, "partial segments: one-segment variant only");
     static_assert(RT == 1 || RT == 2 || RT == 4, "one DPP row of 16 lanes per residual row");
     constexpr int X0 = WB, X1 = WB + 16, X2 = WB + 32, A0 = WB + 48, A1 = WB + 64, U0 = WB + 80;
     extern __shared__ float smem[];                 // seg[2][RT][S]
@@ -716,15 +719,16 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
     if constexpr (RT >= 2) win_zero16<U0 + 16>();
     if constexpr (RT >= 4) { win_zero16<U0 + 32>(); win_zero16<U0 + 48>(); }
     win_zero16<X2>();
-    win_load16<X0>(xload, lane_off);
-    win_load16<A0>(aload, lane_off);
+    if constexpr (NQ < 4) { win_zero16<X0>(); win_zero16<X1>(); }     // (the quarters no load ever writes)
+    win_load16<X0, NQ>(xload, lane_off);
+    win_load16<A0, NQ>(aload, lane_off);
     {
         const int64_t adv = (1 < p.d) ? p.m_pad : 0;   // a one-column layer re-reads column 0
         xload += adv;
         aload += adv;
     }
-    win_load16<X1>(xload, lane_off);
-    win_load16<A1>(aload, lane_off);
+    win_load16<X1, NQ>(xload, lane_off);
+    win_load16<A1, NQ>(aload, lane_off);
 
 #ifdef GPFQ_STAMPS
     // diagnostic build only: cycles per phase of a step, summed by wave 0 and the last wave of block 0 into status[16..]
@@ -753,16 +757,16 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         GPFQ_RSTAMP(0)
         const bool more = t + 1 < p.d;
         float* seg = smem + (t & 1) * RT * S;
-        win_wait<8>();                              // column t has landed; the eight loads of column t+1 stay in flight
+        win_wait<2 * NQ>();                              // column t has landed; the eight loads of column t+1 stay in flight
         GPFQ_RSTAMP(1)
         float acc[RT];
         if constexpr (RT == 1) {
-            acc[0] = win_sweep16<U0, XP, AC, XC>(qprev[0], wcur[0]);
+            acc[0] = win_sweep16<U0, XP, AC, XC, NQ>(qprev[0], wcur[0]);
         } else {                                    // rows in interleaved pairs: 80 instructions per pair instead of 96
-            const v2f a01 = win_sweep16_pair<U0, XP, AC, XC>(qprev[0], qprev[1], wcur[0], wcur[1]);
+            const v2f a01 = win_sweep16_pair<U0, XP, AC, XC, NQ>(qprev[0], qprev[1], wcur[0], wcur[1]);
             acc[0] = a01.x; acc[1] = a01.y;
             if constexpr (RT >= 4) {
-                const v2f a23 = win_sweep16_pair<U0 + 32, XP, AC, XC>(qprev[2], qprev[3], wcur[2], wcur[3]);
+                const v2f a23 = win_sweep16_pair<U0 + 32, XP, AC, XC, NQ>(qprev[2], qprev[3], wcur[2], wcur[3]);
                 acc[2] = a23.x; acc[3] = a23.y;
             }
         }
@@ -774,8 +778,8 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
             xload += adv;
             aload += adv;
         }
-        win_load4<XP, 0>(xload, lane_off);
-        win_load4<AC, 0>(aload, lane_off);
+        win_load4<XP, 0, NQ>(xload, lane_off);
+        win_load4<AC, 0, NQ>(aload, lane_off);
         float v1 = 0.0f;                            // ONE: the dot products, row r in lane row r
         if constexpr (RT == 1) {
             const float sg = wave_tree64_lane63(acc[0]);
@@ -789,13 +793,13 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         float uni = 0.0f;
         if (MODE == MODE_STOCHASTIC)
             uni = philox_uniform(p.seed, p.row_id0 + (uint64_t)(grow0 + ((r16 < RT && row0 + r16 < p.Ng) ? r16 : 0)), (uint64_t)t);
-        win_load4<XP, 1>(xload, lane_off);
-        win_load4<AC, 1>(aload, lane_off);
+        win_load4<XP, 1, NQ>(xload, lane_off);
+        win_load4<AC, 1, NQ>(aload, lane_off);
         GPFQ_RSTAMP(3)
         if constexpr (!ONE) __syncthreads();
         GPFQ_RSTAMP(4)
-        win_load4<XP, 2>(xload, lane_off);
-        win_load4<AC, 2>(aload, lane_off);
+        win_load4<XP, 2, NQ>(xload, lane_off);
+        win_load4<AC, 2, NQ>(aload, lane_off);
         // the slot tree in every wave, all RT rows at once: lane = 16 * row + slot; the other lanes hold +0.0f, so the
         // four levels need no tests
         float v;
@@ -869,8 +873,8 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
                 }
             }
         }
-        win_load4<XP, 3>(xload, lane_off);
-        win_load4<AC, 3>(aload, lane_off);
+        win_load4<XP, 3, NQ>(xload, lane_off);
+        win_load4<AC, 3, NQ>(aload, lane_off);
         if (!more) return false;
 #pragma unroll
         for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
@@ -953,6 +957,19 @@ GPFQ_DEFINE_RESIDENT_MODES(1, 16, 32, "v127")
 GPFQ_DEFINE_RESIDENT_ONE_MODES(1, 160)
 GPFQ_DEFINE_RESIDENT_ONE_MODES(2, 144)
 GPFQ_DEFINE_RESIDENT_ONE_MODES(4, 112)
+// ... and of m <= 256 / 512 samples (one / two quarters of the segment): half or a quarter of the loads and of the sweep
+#define GPFQ_DEFINE_RESIDENT_ONE_Q(RT, MODE, WB, NQ)                                                              \
+    __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(WB / 2)))                                \
+    gpfq_resident_rt##RT##_m##MODE##_w1q##NQ(const SlabParams p)                                                 \
+    {                                                                                                             \
+        asm volatile("" ::: "v255");                                                                              \
+        resident_body<RT, MODE, WB, true, NQ>(p);                                                                 \
+    }
+#define GPFQ_DEFINE_RESIDENT_ONE_Q_MODES(RT, WB, NQ)                                                              \
+    GPFQ_DEFINE_RESIDENT_ONE_Q(RT, 0, WB, NQ) GPFQ_DEFINE_RESIDENT_ONE_Q(RT, 1, WB, NQ)                           \
+    GPFQ_DEFINE_RESIDENT_ONE_Q(RT, 2, WB, NQ) GPFQ_DEFINE_RESIDENT_ONE_Q(RT, 3, WB, NQ)
+GPFQ_DEFINE_RESIDENT_ONE_Q_MODES(1, 160, 1) GPFQ_DEFINE_RESIDENT_ONE_Q_MODES(2, 144, 1) GPFQ_DEFINE_RESIDENT_ONE_Q_MODES(4, 112, 1)
+GPFQ_DEFINE_RESIDENT_ONE_Q_MODES(1, 160, 2) GPFQ_DEFINE_RESIDENT_ONE_Q_MODES(2, 144, 2) GPFQ_DEFINE_RESIDENT_ONE_Q_MODES(4, 112, 2)
 
 // ------------------------------------------------------------------------------------------------
 // Streaming plan: any (N, m).  The residual rows stay in the caller's U (HBM / L2 / Infinity Cache) and

@@ -241,7 +241,9 @@ def test_one_segment_rows(qnn, oracle_mod, monkeypatch, rt):
     no barrier -- with 1, 2 or 4 rows per wave: ragged last tile, history flush across 64-step blocks, grouped, all
     four quantizers (the stochastic one against the oracle's Philox stream)."""
     from quantized_neural_nets_amd import _lib
-    for (N, d, m, groups, reg) in [(13, 150, 700, 1, None), (9, 70, 1024, 3, "L0"), (7, 65, 333, 1, "L1")]:
+    # m <= 256 / <= 512: the variants that load and sweep one / two quarters of the segment (exact: the rest is zero padding)
+    for (N, d, m, groups, reg) in [(13, 150, 700, 1, None), (9, 70, 1024, 3, "L0"), (7, 65, 333, 1, "L1"), (11, 90, 200, 1, None),
+                                   (6, 70, 256, 2, None), (5, 66, 512, 1, "L0"), (8, 33, 257, 1, None), (4, 20, 32, 1, "L1")]:
         case = dict(name="wave", N=N, d=d, m=m, bits=4, scalar=1.16, percentile=1.0, reg=reg, lamb=0.02, groups=groups,
                     first_layer=False, zero_every=9, seed=12)
         W, A, X = gi.make_inputs(case)
