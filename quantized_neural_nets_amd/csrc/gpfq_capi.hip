@@ -81,7 +81,8 @@ int coop_wave_bound(int RT, int NW, int C)
 {
     if (RT == 1) return (NW <= 12 && C <= 128) ? 12 : 16;    // (16: the variant that gathers four members per lane)
     if (NW <= 8) return 8;
-    return (NW <= 12 || RT != 2) ? 12 : 16;
+    if (RT == 4) return NW <= 12 ? 12 : 16;             // (16: the LDS-staged variant, exactly 13 sweep waves)
+    return NW <= 12 ? 12 : 16;
 }
 
 int pow2_ceil_host(int v)
@@ -105,7 +106,7 @@ double slab_step_cost(int RT, int waves, int C, int wgs)
     // reducer went on its instruction diet; re-measured on the shapes that run in rounds: 50 segments 4 rows x 8 members
     // 2.35 us, 197 segments 4 x 32 2.26, 785 segments 2 x 64 3.45; 91 segments 2 x 8 2.20 against 4 x 16 2.50, and a
     // 32-row shard of them 1 x 8 2.06 against 2 x 16 2.26)
-    return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.45 + 0.004 * (n - 16) : 0.0) + (C >= 32 ? 0.1 : 0.0) + (C >= 64 ? 0.9 : 0.0) + (((RT == 4 && waves > 8) || (RT == 2 && waves > 12)) ? 0.43 : 0.0);
+    return 0.74 + 0.119 * RT + 0.102 * waves + (n > 16 ? 0.45 + 0.004 * (n - 16) : 0.0) + (C >= 32 ? 0.1 : 0.0) + (C >= 64 ? 0.9 : 0.0) + (((RT == 4 && waves > 8) || (RT == 2 && waves > 12)) ? 0.43 : 0.0) + ((RT == 4 && waves > 12) ? 0.6 : 0.0);
 }
 
 // Rows per workgroup of the resident plan: the rows of a workgroup share every column load, and the CU's vector-memory
@@ -175,11 +176,13 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullpt
         if (force_rt && RT != force_rt) continue;
         const int64_t tiles = (Ng + RT - 1) / RT;
         // the reducer gathers RT * C <= 128 granules (two per lane) -- 256 in the one-row 16-wave variant (four per lane)
-        for (int C = (RT == 1 ? 256 : 128 / RT); C >= 2; C >>= 1) {
+        for (int C = (RT == 1 ? 256 : (RT == 4 ? 64 : 128 / RT)); C >= 2; C >>= 1) {
             if (force_c && C != force_c) continue;
             if (C > S || C > capacity) continue;
             const int NW = (S + C - 1) / C;
             if (RT == 1 && (C > 128 || NW > 12) && (C < 4 || NW > 15)) continue;   // (that variant gathers in fours)
+            if (RT == 4 && C == 64 && NW != 13) continue;                          // (256 granules: the LDS-staged variant only)
+            if (RT == 4 && NW == 13 && env_int("GPFQ_COOP_NO_LDS", 0)) continue;
             if (NW > slab_max_waves(true, RT) || pow2_ceil_host(S) / C > 16) continue;
             const int64_t tiles_round = tiles * C <= capacity ? tiles : capacity / C;
             const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
@@ -420,6 +423,7 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
     }
     GPFQ_PICK(1, 12) GPFQ_PICK(1, 16) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(2, 16) GPFQ_PICK(4, 8)
 #undef GPFQ_PICK
+    if (RT == 4 && maxw == 16) return nullptr;      // (coop_kernel_lds)
     if (RT == 4 && maxw == 12) {                    // (no stochastic variant: see GPFQ_DEFINE_COOP in gpfq_loop_kernels.h)
         switch (mode) {
         case gpfq::MODE_SOFT: return gpfq::gpfq_coop_rt4_m1_w12;
@@ -429,6 +433,17 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
         }
     }
     return nullptr;
+}
+
+// four rows at 13 sweep waves, columns staged through LDS (gpfq_loop_kernels.h coop_lds_body)
+SlabKernel coop_kernel_lds(int mode, bool quad)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return quad ? gpfq::gpfq_coop_rt4_m1_w16lq : gpfq::gpfq_coop_rt4_m1_w16l;
+    case gpfq::MODE_HARD: return quad ? gpfq::gpfq_coop_rt4_m2_w16lq : gpfq::gpfq_coop_rt4_m2_w16l;
+    case gpfq::MODE_STOCHASTIC: return quad ? gpfq::gpfq_coop_rt4_m3_w16lq : gpfq::gpfq_coop_rt4_m3_w16l;
+    default: return quad ? gpfq::gpfq_coop_rt4_m0_w16lq : gpfq::gpfq_coop_rt4_m0_w16l;
+    }
 }
 
 // one row per group, 12 waves (gpfq_loop_kernels.h GPFQ_DEFINE_COOP_GROUPED)
@@ -446,12 +461,19 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
 {
     const int RT = pl.RT;
     const int maxw = pl.grouped ? 12 : coop_wave_bound(RT, pl.waves, pl.C);
-    SlabKernel kern = pl.grouped ? coop_kernel_grouped(mode) : coop_kernel(RT, mode, maxw);
-    if (!kern || pl.waves > maxw) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
+    const bool lds = RT == 4 && maxw == 16 && !pl.grouped;
+    SlabKernel kern = pl.grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * pl.C > 128) : coop_kernel(RT, mode, maxw);
+    if (!kern || pl.waves > maxw || (lds && pl.waves != 13))
+        return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
     // one more wave for the reducer role when the variant's wave bound allows it
     const int nwaves = pl.waves + ((pl.waves + 1 <= maxw && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
     const int threads = 64 * nwaves;
-    const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1) + 2 * RT * 64);
+    const size_t shm = sizeof(float) * (2 * RT * (size_t)nwaves + 2 * (RT + 1) + 2 * RT * 64) +
+                       (lds ? (size_t)pl.waves * 3 * 4096 : 0);          // + three 4-KB column buffers per sweep wave
+    if (lds) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (ea != hipSuccess) return hip_fail(ea, "dynamic LDS size");
+    }
     const int nblocks = pl.tiles * pl.C;
     // every workgroup must be resident at once: check the grid against the occupancy query (the query is
     // known to over-report by one only near the SGPR limit of >= 6 waves per SIMD; these kernels run at
@@ -553,7 +575,7 @@ int launch_slab(const Plan& pl, const gpfq::LoopParams& p, int groups, bool vec,
 int slab_max_waves(bool coop, int RT)
 {
     if (!coop) return 16;
-    return RT <= 2 ? 16 : 12;
+    return RT <= 2 ? 16 : 13;                           // (four rows: 13 sweep waves x 12 KB of LDS is what a CU holds)
 }
 
 int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scratch_bytes, hipStream_t st)

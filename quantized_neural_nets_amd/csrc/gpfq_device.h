@@ -520,6 +520,37 @@ __device__ __forceinline__ v2f win_sweep16_pair(float q0, float q1, float w0, fl
     return acc;
 }
 #undef GPFQ_SP
+// One quarter (four elements per lane) of the pair sweep with the COLUMNS IN ORDINARY REGISTERS -- read back from LDS by
+// the variant that stages its columns there (coop_lds_body: four rows at 13 waves leave no room for a register window).
+// UPC = first window register of the quarter of the pair: UP + 8 c.  xp / a / x: elements (0, 1) and (2, 3) as pairs.
+#define GPFQ_SL(u0, u1, xp, a, x, sel)                                                                              \
+    "v_pk_mul_f32 %1, %3, " xp " op_sel:[0," #sel "] op_sel_hi:[1," #sel "]\n\t"                                     \
+    "v_pk_mul_f32 %2, %4, " a " op_sel:[0," #sel "] op_sel_hi:[1," #sel "]\n\t"                                      \
+    "v_pk_add_f32 v[%c11+" #u0 ":%c11+" #u1 "], v[%c11+" #u0 ":%c11+" #u1 "], %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"       \
+    "v_pk_add_f32 v[%c11+" #u0 ":%c11+" #u1 "], v[%c11+" #u0 ":%c11+" #u1 "], %2\n\t"                                 \
+    "v_pk_fma_f32 %0, v[%c11+" #u0 ":%c11+" #u1 "], " x ", %0 op_sel:[0," #sel ",0] op_sel_hi:[1," #sel ",1]\n\t"
+template <int UPC>
+__device__ __forceinline__ void win_sweep4_pair_lds(v2f& acc, v2f qq, v2f ww, v2f xp01, v2f xp23, v2f a01, v2f a23, v2f x01, v2f x23)
+{
+    v2f t0, t1;
+    asm volatile(GPFQ_SL(0, 1, "%5", "%7", "%9", 0) GPFQ_SL(2, 3, "%5", "%7", "%9", 1)
+                 GPFQ_SL(4, 5, "%6", "%8", "%10", 0) GPFQ_SL(6, 7, "%6", "%8", "%10", 1) "s_nop 0"
+                 : "+v"(acc), "=&v"(t0), "=&v"(t1)
+                 : "v"(qq), "v"(ww), "v"(xp01), "v"(xp23), "v"(a01), "v"(a23), "v"(x01), "v"(x23), "n"(UPC));
+}
+#undef GPFQ_SL
+// ... and the pending subtraction of the last step for such a quarter: u = u - q * x_{d-1}, both rows of the pair
+#define GPFQ_FL(u0, u1, x, sel)                                                                                     \
+    "v_pk_mul_f32 %0, %1, " x " op_sel:[0," #sel "] op_sel_hi:[1," #sel "]\n\t"                                      \
+    "v_pk_add_f32 v[%c4+" #u0 ":%c4+" #u1 "], v[%c4+" #u0 ":%c4+" #u1 "], %0 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+template <int UPC>
+__device__ __forceinline__ void win_final_sub4_pair_lds(v2f qq, v2f x01, v2f x23)
+{
+    v2f t0;
+    asm volatile(GPFQ_FL(0, 1, "%2", 0) GPFQ_FL(2, 3, "%2", 1) GPFQ_FL(4, 5, "%3", 0) GPFQ_FL(6, 7, "%3", 1) "s_nop 0"
+                 : "=&v"(t0) : "v"(qq), "v"(x01), "v"(x23), "n"(UPC));
+}
+#undef GPFQ_FL
 // the pending subtraction of the last step, in place: u = u - q * x_{d-1}                          (step_algorithm.py:148)
 template <int U, int XL>
 __device__ __forceinline__ void win_final_sub16(float q)

@@ -141,7 +141,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
     // Gather layout: lane = stride * row + member.  More than 64 granules (RT * C <= 128: long rows that run in rounds)
     // are gathered two members per lane, 2j and 2j+1 -- adjacent member blocks, the pair the first level of the tree
     // over the members adds anyway.
-    static_assert(!QUAD || RT == 1, "four members per lane: one-row variant only");
+    static_assert(!QUAD || RT == 1 || RT == 4, "four members per lane: the one-row and the LDS-staged four-row variants");
     const bool wide = !QUAD && RT * C > 64;
     const int per_row = QUAD ? C >> 2 : (wide ? C >> 1 : C);  // lanes per row
     const int sh = per_row <= 16 ? 4 : (per_row <= 32 ? 5 : 6);   // log2 of the lane stride of a row in the gather
@@ -177,7 +177,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
             unsigned long long g[4];
             for (;;) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) g[i] = __hip_atomic_load(src + (want ? i : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 4; ++i) g[i] = __hip_atomic_load(src + (want ? i * RT : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned long long ok = ~0ull;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64((unsigned)(g[i] >> 32) == epoch);
@@ -292,11 +292,14 @@ __device__ __forceinline__ void store_segment_sumsq(float* usq, int64_t slot, co
 // Tail of the window kernels for one row: the pending subtraction of the last step (in place, in the window), then the
 // residual leaves the registers four elements at a time (step_algorithm.py:148), with the fused sum of squares.
 // STRIDE 2: the row is one of an interleaved pair (win_sweep16_pair): its registers are U, U + 2, U + 4, ...
-template <int U, int XL, int STRIDE = 1>
+// SUB false: the caller has done the pending subtraction itself (its x_{d-1} is not in the window).
+template <int U, int XL, int STRIDE = 1, bool SUB = true>
 __device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, bool valid, int64_t grow, int seg, int lane)
 {
-    if constexpr (STRIDE == 1) win_final_sub16<U, XL>(qlast);
-    else win_final_sub16_s2<U, XL>(qlast);
+    if constexpr (SUB) {
+        if constexpr (STRIDE == 1) win_final_sub16<U, XL>(qlast);
+        else win_final_sub16_s2<U, XL>(qlast);
+    }
     if (!valid) return;
     const int64_t kbase = (int64_t)seg * kSeg + 4 * lane;      // computed here: nothing 64-bit stays live across the loop
     float* Urow = p.U + grow * p.ldu;
@@ -607,6 +610,172 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
     else if (k == 1) finish(I1{});
     else if constexpr (DEPTH == 2) finish(I2{});
 }
+
+// FOUR rows at 13 sweep waves: the variant for rows whose members need a 13th wave (m = 1024 (L/4 + 1), L = 14^2 4^k --
+// every 1x1 convolution of ResNet-50 at batch 1024 -- is 12.27..12.5 segments per member at any power-of-two member count).
+// The 128-register budget of 13..16 waves holds the four residual rows (64) and nothing like a column window, so the
+// columns live in LDS: gfx950's global_load_lds_dwordx4 writes a wave's 1 KB quarters straight into its three 4 KB
+// buffers (x ring of two, a), one step ahead (column t+1 is requested when sweep t has read its buffers for the last
+// time and has the whole exchange to land), and the sweep reads them back 16 bytes per lane per quarter (conflict-free).
+// 13 x 12 KB = 156 of the CU's 160 KB.  Same arithmetic, same order: the interleaved pair sweep, a quarter at a time.
+template <int MODE, bool QUAD>
+__device__ __forceinline__ void coop_lds_body(const SlabParams& p)
+{
+    constexpr int RT = 4, U0 = 64;                  // window = the four residual rows only (two interleaved pairs)
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [sweep waves][3][1024], seg[2][RT][NW], qs[2][RT+1], history
+    const int NW = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int S = p.S, C = p.C;
+    const int P = pow2_ceil(S);
+    if (*static_cast<volatile const int*>(p.status) != 0) return;       // (a layer in rounds stops at the first timed-out launch)
+    int tile, c;
+    if (p.xcd_tiles && (p.tiles & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = (j / C) * 8 + xcd;
+        c = j % C;
+    } else {
+        tile = blockIdx.x / C;
+        c = blockIdx.x % C;
+    }
+    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
+    const int n_own = seg_hi - seg_lo;
+    const int max_own = (S + C - 1) / C;
+    const int rwave = NW > max_own ? max_own : 0;
+    const bool active = wave < n_own;
+    const int myseg = seg_lo + (active ? wave : 0);
+    const int nl = P / C;
+    const SlotMap smap = make_slot_map(S, P, c * nl, 1, lane & 15, nl);
+
+    float* cols = smem + (size_t)(wave < max_own ? wave : 0) * 3072;    // this wave's x ring (2 x 1024) and a buffer (1024)
+    float* segs = smem + (size_t)max_own * 3072;    // [2][RT][NW]
+    float* qs = segs + 2 * RT * NW;                 // [2][RT + 1], then the history [2*RT][64]
+
+    const int row0 = tile * RT;
+    const int64_t grow0 = row0;
+    const kfloat* nrm = as_scalar(p.nrm2);
+    const kfloat* wrow[RT];
+    float qprev[RT], wcur[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int64_t gr = grow0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
+        wrow[r] = as_scalar(p.W + gr * p.ldw);
+        qprev[r] = 0.0f;
+        wcur[r] = wrow[r][0];
+    }
+    float n2cur = nrm[0];
+    float in2cur = nrm[1];
+    win_zero16<U0>(); win_zero16<U0 + 16>(); win_zero16<U0 + 32>(); win_zero16<U0 + 48>();
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    // one column segment (1024 floats) of this wave into one LDS buffer: lane l brings elements 256 q + 4 l .. + 3 of quarter q
+    auto dma = [&](float* buf, const float* g) {
+        lds_ptr_t l = (lds_ptr_t)(uintptr_t)buf;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 3072, 0);
+    };
+    const float* xg = p.XT + (int64_t)myseg * kSeg + 4 * lane;
+    const float* ag = p.AT + (int64_t)myseg * kSeg + 4 * lane;
+    if (active) {
+        // x_0 -> ring[0], a_0 -> a; ring[1] = x_{-1} = 0 (q_{-1} = 0)
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<float4*>(cols + 1024 + 256 * q4 + 4 * lane) = z;
+        dma(cols, xg);
+        dma(cols + 2048, ag);
+    }
+    int t = 0;
+    bool gave_up = false;
+    for (;;) {
+        const int par = t & 1;
+        const bool more = t + 1 < p.d;
+        float* seg = segs + par * RT * NW;
+        if (active) {
+            const float* xc = cols + par * 1024;         // x_t
+            const float* xp = cols + (par ^ 1) * 1024;   // x_{t-1}
+            const float* ab = cols + 2048;               // a_t
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // column t has landed in LDS
+            v2f acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
+            const v2f qq01 = {qprev[0], qprev[1]}, ww01 = {wcur[0], wcur[1]};
+            const v2f qq23 = {qprev[2], qprev[3]}, ww23 = {wcur[2], wcur[3]};
+            auto quarter = [&](auto c_) {
+                constexpr int cq = decltype(c_)::value;
+                const float4 x4 = *reinterpret_cast<const float4*>(xc + 256 * cq + 4 * lane);
+                const float4 a4 = *reinterpret_cast<const float4*>(ab + 256 * cq + 4 * lane);
+                const float4 p4 = *reinterpret_cast<const float4*>(xp + 256 * cq + 4 * lane);
+                const v2f x01 = {x4.x, x4.y}, x23 = {x4.z, x4.w}, a01 = {a4.x, a4.y}, a23 = {a4.z, a4.w};
+                const v2f p01 = {p4.x, p4.y}, p23 = {p4.z, p4.w};
+                win_sweep4_pair_lds<U0 + 8 * cq>(acc01, qq01, ww01, p01, p23, a01, a23, x01, x23);
+                win_sweep4_pair_lds<U0 + 32 + 8 * cq>(acc23, qq23, ww23, p01, p23, a01, a23, x01, x23);
+                __builtin_amdgcn_sched_barrier(0);  // one quarter's twelve registers of columns at a time (the budget is 64)
+            };
+            quarter(std::integral_constant<int, 0>{});
+            quarter(std::integral_constant<int, 1>{});
+            quarter(std::integral_constant<int, 2>{});
+            quarter(std::integral_constant<int, 3>{});
+            const float acc[RT] = {acc01.x, acc01.y, acc23.x, acc23.y};
+            const float tot = wave_tree64_rows<RT>(acc);
+            if ((lane & 15) == 0 && (lane >> 4) < RT) seg[(lane >> 4) * NW + wave] = tot;
+            // column t+1 into the buffers this sweep has read for the last time (the last step re-reads its own)
+            const int64_t adv = more ? p.m_pad : 0;
+            xg += adv;
+            ag += adv;
+            dma(cols + (par ^ 1) * 1024, xg);
+            dma(cols + 2048, ag);
+        }
+        __syncthreads();
+        float wn[RT];
+        const int tn = more ? t + 1 : t;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wn[r] = sload(wrow[r], 4u * (unsigned)tn);
+        const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
+        if (wave == rwave)
+            gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
+                                                                                n2cur, in2cur, row0, grow0, seg_lo, gave_up);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
+        if (!more) break;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) wcur[r] = wn[r];
+        n2cur = n2n;
+        in2cur = in2n;
+        ++t;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!active) return;
+    {   // the pending subtraction of the last step: u -= q_{d-1} x_{d-1}, x_{d-1} from its ring buffer
+        const float* xl = cols + (t & 1) * 1024;
+        const v2f qq01 = {qprev[0], qprev[1]}, qq23 = {qprev[2], qprev[3]};
+        auto quarter = [&](auto c_) {
+            constexpr int cq = decltype(c_)::value;
+            const float4 x4 = *reinterpret_cast<const float4*>(xl + 256 * cq + 4 * lane);
+            const v2f x01 = {x4.x, x4.y}, x23 = {x4.z, x4.w};
+            win_final_sub4_pair_lds<U0 + 8 * cq>(qq01, x01, x23);
+            win_final_sub4_pair_lds<U0 + 32 + 8 * cq>(qq23, x01, x23);
+        };
+        quarter(std::integral_constant<int, 0>{});
+        quarter(std::integral_constant<int, 1>{});
+        quarter(std::integral_constant<int, 2>{});
+        quarter(std::integral_constant<int, 3>{});
+    }
+    finish_row_w<U0, 0, 2, false>(p, qprev[0], row0 < p.Ng, grow0, myseg, lane);
+    finish_row_w<U0 + 1, 0, 2, false>(p, qprev[1], row0 + 1 < p.Ng, grow0 + 1, myseg, lane);
+    finish_row_w<U0 + 32, 0, 2, false>(p, qprev[2], row0 + 2 < p.Ng, grow0 + 2, myseg, lane);
+    finish_row_w<U0 + 33, 0, 2, false>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, myseg, lane);
+}
+
+#define GPFQ_DEFINE_COOP_LDS(MODE, QUADV, SUFFIX)                                                                 \
+    __global__ void __launch_bounds__(64 * 16) __attribute__((amdgpu_num_vgpr(64 / 2)))                            \
+    gpfq_coop_rt4_m##MODE##_w16##SUFFIX(const SlabParams p)                                                       \
+    {                                                                                                             \
+        asm volatile("" ::: "v127");                                                                              \
+        coop_lds_body<MODE, QUADV>(p);                                                                            \
+    }
+GPFQ_DEFINE_COOP_LDS(0, false, l) GPFQ_DEFINE_COOP_LDS(1, false, l) GPFQ_DEFINE_COOP_LDS(2, false, l) GPFQ_DEFINE_COOP_LDS(3, false, l)
+GPFQ_DEFINE_COOP_LDS(0, true, lq) GPFQ_DEFINE_COOP_LDS(1, true, lq) GPFQ_DEFINE_COOP_LDS(2, true, lq) GPFQ_DEFINE_COOP_LDS(3, true, lq)
 
 // One __global__ per (rows per workgroup, quantizer, wave bound): see GPFQ_DEFINE_RESIDENT below for the attribute.
 #define GPFQ_DEFINE_COOP(RT, MODE, MAXW, DEPTH, WB, LAST)                                                         \

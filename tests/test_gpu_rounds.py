@@ -31,7 +31,12 @@ CASES = [
      "two rows x 13 sweep waves: the 16-wave variant"),
     ((70, 16, 201728), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "32"}, "coop RT=4 C=32 waves=7 S=197 grid=256 rounds=3",
      "128 granules: two gathered members per lane; the last tile has 2 valid rows"),
-    ((21, 10, 803840), {}, "coop RT=2 C=64 waves=13 S=785 grid=256 rounds=3", "16-wave variant AND 128 granules, odd row count"),
+    ((21, 10, 803840), {"GPFQ_COOP_RT": "2"}, "coop RT=2 C=64 waves=13 S=785 grid=256 rounds=3", "16-wave variant AND 128 granules, odd row count"),
+    ((300, 24, 51200), {}, "coop RT=4 C=4 waves=13 S=50 grid=256 rounds=2",
+     "four rows x 13 sweep waves, columns staged through LDS (global_load_lds); 256 rows per round, the last round partial"),
+    ((70, 16, 201728), {}, "coop RT=4 C=16 waves=13 S=197 grid=256 rounds=2", "the same variant with 16 members (64 granules)"),
+    ((21, 10, 803840), {}, "coop RT=4 C=64 waves=13 S=785 grid=256 rounds=2",
+     "the same variant with 64 members: 256 granules gathered four per lane; 16 rows per round, 5 in the last"),
     ((20, 10, 720384), {}, "coop RT=2 C=64 waves=11 S=704 grid=256 rounds=3", "128 granules at 64 members (VGG-16 conv1 rows)"),
     ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
     ((12, 6, 1440768), {}, "coop RT=1 C=128 waves=11 S=1407 grid=256 rounds=6",
