@@ -67,6 +67,11 @@ _add_big("g6_48x300x5000_hard_b3", 48, 300, 5000, bits=3, reg="L0", lamb=0.02)
 _add_big("g6_136x24x51200_msq_b4", 136, 24, 51200)                         # 50 segments, two rounds of 128 rows (16-wave two-row kernel)
 _add_big("g6_11x10x803840_msq_b4", 11, 10, 803840)                         # 785 segments, 64 members, 128 granules, two rounds of 8 rows
 _add_big("g6_40x12x201728_soft_b2", 40, 12, 201728, bits=2, reg="L1", lamb=0.1)   # 197 segments, 32 members x 4 rows, two rounds
+# one row on many workgroups (EfficientNet-B1's first layers at batch 1024) and depthwise rows long enough for the grouped
+# cooperative kernel (one row per group, every group its own 9 columns)
+_add_big("g6_3x4x3212288_msq_b4", 3, 4, 3212288)                            # 3137 segments: 256 members, four gathered per lane
+_add_big("g6_12x6x1440768_soft_b2", 12, 6, 1440768, bits=2, reg="L1", lamb=0.1)    # 1407 segments: 128 members, two per lane
+_add_big("g6_dw24x9x100352_soft_b2", 24, 9, 100352, bits=2, reg="L1", lamb=0.1, groups=24)   # depthwise, 98 segments per group
 
 
 def make_inputs(case, seed_offset=0):

@@ -24,21 +24,22 @@ def _t(a):
 @pytest.mark.parametrize("name", sorted(gi.BIG_CASES))
 @pytest.mark.parametrize("plan", [0, 1, 3])
 def test_big_case_against_reference_and_oracle(oracle_mod, name, plan):
-    """Every G6 shape has m >= 2048, so the cooperative plan (3) applies to all of them: the cooperative kernels meet
-    reference-held data on six fixtures here, not three."""
+    """Every G6 shape has m >= 2048, so the cooperative plan (3) applies to all of them: every cooperative variant --
+    plain, in rounds, LDS-staged, 128 and 256 members of one row, grouped (depthwise) -- meets reference-held data here."""
     from quantized_neural_nets_amd import StepAlgorithm, _lib
     case, (W, A, X), fx, meta = gi.load_big_case(name)
     K = 2 ** (case["bits"] - 1)
-    desc = _lib.describe_plan(case["N"], case["d"], case["m"], 1, plan)
+    g = case["groups"]
+    desc = _lib.describe_plan(case["N"], case["d"], case["m"], g, plan)
     r = StepAlgorithm._quantize_layer_ex(_t(W), _t(A), _t(X), case["m"], case["scalar"] / K, K, case["percentile"],
-                                         case["reg"], case["lamb"], 1, False, torch.device(DEV), plan=plan)
+                                         case["reg"], case["lamb"], g, False, torch.device(DEV), plan=plan)
     torch.cuda.synchronize()
     got = dict(idx=r["idx"].cpu().numpy(), U=r["U"].cpu().numpy(), step=float(r["step"]),
                quantize_error=float(r["quantize_error"]), relative_quantize_error=float(r["relative_quantize_error"]),
-               relative_adder=r["relative_adder"].cpu().numpy())
+               relative_adder=None if g > 1 else r["relative_adder"].cpu().numpy())
     rep = check_big_case(name, got, "HIP[%s]" % desc.split(" d=")[0])
     # and the oracle, bit for bit (the canonical order is shared)
-    o = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"], 1)
+    o = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"], g)
     assert np.array_equal(got["idx"].astype(np.int16), o["idx"])
     assert np.array_equal(got["U"], o["U"])
     assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))

@@ -122,12 +122,15 @@ def check_big_case(name, got, where):
     assert np.array_equal(ck["U_crc32"][ok], fx["U_crc32"][ok]), "residual rows differ from the reference where indices agree"
     assert np.array_equal(ck["U_head"][ok], fx["U_head"][ok])
     if not rep["rows_diverged"]:
-        qe = float(np.sqrt(ck["U_sumsq"].sum()))
+        # (grouped layers: the mean of the groups' norms, step_algorithm.py:238-241)
+        qe = float(np.sqrt(ck["U_sumsq"].reshape(case["groups"], -1).sum(1)).mean())
         # qe is the fp64 norm of a residual that equals the reference's bit for bit (checksums above); the fixture holds
         # the reference's own fp32 torch.linalg.norm (step_algorithm.py:216), whose accumulation error grows with the
         # element count (absorption: it comes out LOW): within 1e-4 up to 4 M elements, 2.1e-4 / 2.6e-4 / 3.7e-4 low on the 7.0 /
-        # 8.1 / 8.8 M elements of the three long-row fixtures -- there the bound is 1e-3
-        tol = 1e-4 if np.asarray(got["U"]).size <= (1 << 22) else 1e-3
+        # 8.1 / 8.8 M elements of the three long-row fixtures -- there the bound is 1e-3 -- and 1.8e-3 low on the 3 x 3.2 M
+        # elements of the one-row-per-chip fixture (657.42 against 658.61; its norm runs down 3.2 M rows of 3): 3e-3
+        n_el = np.asarray(got["U"]).size
+        tol = 1e-4 if n_el <= (1 << 22) else (1e-3 if n_el <= 9000000 else 3e-3)
         assert abs(qe - float(fx["quantize_error"])) <= tol * float(fx["quantize_error"])
         if got.get("quantize_error") is not None:
             assert abs(float(got["quantize_error"]) - float(fx["quantize_error"])) <= tol * float(fx["quantize_error"])
@@ -152,7 +155,7 @@ def test_big_fixtures_present():
 def test_big_case_against_reference(oracle_mod, name):
     case, (W, A, X), fx, meta = gi.load_big_case(name)
     K = 2 ** (case["bits"] - 1)
-    r = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"], 1)
+    r = oracle_mod.quantize_layer(W, A, X, case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"], case["groups"])
     check_big_case(name, r, "oracle")
 
 

@@ -195,20 +195,26 @@ def gen_big_case(SA, name):
     """Headline-scale case: ONE run of the reference on seed offset 0 -- no seed search, no margin requirement.
     Stores int8 indices, the step, the error outputs and per-row digests of U (gi.row_checksums) instead of Q / U."""
     case = gi.BIG_CASES[name]
-    assert case["groups"] == 1
     W, A, X = gi.make_inputs(case, 0)
     N, d, m = case["N"], case["d"], case["m"]
     K = 2 ** (case["bits"] - 1)
     step_base = case["scalar"] / K
     Wt, At, Xt = torch.from_numpy(W.copy()), torch.from_numpy(A.copy()), torch.from_numpy(X.copy())
     t0 = time.time()
-    Q, qe, rqe, adder, radder = quiet(SA._quantize_layer, Wt, At, Xt, m, step_base, K, case["percentile"],
-                                      case["reg"], case["lamb"], 1, False, torch.device("cpu"))
+    if case["groups"] == 1:
+        Q, qe, rqe, adder, radder = quiet(SA._quantize_layer, Wt, At, Xt, m, step_base, K, case["percentile"],
+                                          case["reg"], case["lamb"], 1, False, torch.device("cpu"))
+        U = adder.T.contiguous().numpy()            # quantize_adder = U.T  (step_algorithm.py:216)
+    else:
+        # grouped layers: the reference returns no residual (step_algorithm.py:226-237); U comes from its own inner
+        # loop run per group, after checking that loop reproduces _quantize_layer's Q (run_reference_layer)
+        res = run_reference_layer(SA, case, W, A, X)
+        Q, qe, rqe, U = torch.from_numpy(res["Q"]), res["quantize_error"], res["relative_quantize_error"], res["U"]
+        radder = None
     dt = time.time() - t0
     rad = torch.quantile(torch.abs(Wt), case["percentile"], axis=1).mean()
     step = step_base * rad - case["lamb"] / K if case["reg"] == 'L0' else step_base * rad
     Q = Q.numpy().reshape(N, d)
-    U = adder.T.contiguous().numpy()            # quantize_adder = U.T  (step_algorithm.py:216)
     idx = index_of(case, Q, step.item())
     assert np.abs(idx).max() <= 127
     margin = fp64_margin(case, W, A, X, Q, step.item())
@@ -217,7 +223,7 @@ def gen_big_case(SA, name):
     np.savez_compressed(os.path.join(gi.GOLDEN_DIR, name + ".npz"), meta=np.array(json.dumps(meta)),
                         idx=idx.astype(np.int8), step=np.float32(step.item()),
                         quantize_error=np.float32(float(qe)), relative_quantize_error=np.float32(float(rqe)),
-                        relative_adder=radder.numpy().copy(), **gi.row_checksums(U))
+                        **({} if radder is None else {"relative_adder": radder.numpy().copy()}), **gi.row_checksums(U))
     print("%-30s NO seed search: fp64 margin=%.2e step=%.6g levels=%d ref %.1fs (%.4f Mw/s, %d threads)" % (
         name, margin, step.item(), len(np.unique(idx)), dt, N * d / dt / 1e6, torch.get_num_threads()))
 
