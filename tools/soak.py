@@ -26,7 +26,7 @@ def main():
     t0 = time.time()
     bad = 0
     for ci in range(ncases):
-        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise"])
+        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise", "chip_wide"])
         groups = 1
         if fam == "wave":                           # one-segment rows: the resident kernel's one-wave variant, 1 / 2 / 4 rows per wave
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
@@ -45,6 +45,11 @@ def main():
             rt = int(rng.choice([1, 2, 4]))
             os.environ["GPFQ_COOP_RT"] = str(rt)
             os.environ["GPFQ_COOP_C"] = str(int(rng.choice([c for c in (8, 16, 32, 64, 128, 256) if rt * c <= (256 if rt == 1 else 128)])))
+        elif fam == "chip_wide":                    # 256 granules, four gathered per lane: four rows x 64 members (columns
+            if rng.integers(0, 2):                  # staged through LDS), or one row on 256 members; AUTO picks both
+                N, m = int(rng.integers(5, 40)), int(rng.integers(786433, 830000))
+            else:
+                N, m = int(rng.integers(1, 5)), int(rng.integers(2700000, 3300000))
         elif fam == "stream":
             N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
         elif fam == "depthwise":                    # one long row per group: the cooperative one-row kernel's grouped variant
@@ -53,7 +58,7 @@ def main():
         else:
             groups = int(rng.choice([2, 3, 4]))
             N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
-        d = int(rng.integers(1, 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam == "coop_rows" else 40))
+        d = int(rng.integers(1, 5 if fam == "chip_wide" else 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam == "coop_rows" else 40))
         bits = int(rng.choice([2, 3, 4]))
         reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
         plan = 1 if fam == "stream" else 0
@@ -70,7 +75,8 @@ def main():
         os.environ.pop("GPFQ_RESIDENT_RT", None)
         o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
         full = _lib.describe_plan(N, d, m, groups, plan)
-        desc = full.split()[0] + ("+groups" if "groups=" in full else "+rounds" if "rounds=" in full else "")
+        desc = (full.split(" S=")[0] if full.startswith("coop") else full.split()[0]) + (
+            "+groups" if "groups=" in full else "+rounds" if "rounds=" in full else "")
         kinds[desc] = kinds.get(desc, 0) + 1
         os.environ.pop("GPFQ_COOP_RT", None)
         os.environ.pop("GPFQ_COOP_C", None)
