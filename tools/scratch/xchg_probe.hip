@@ -1,0 +1,141 @@
+// xchg_probe.hip -- what one granule exchange of the cooperative kernels costs on its own (gfx950, test tool, not product).
+// 256 workgroups of one wave, one per CU; the C members of a tile publish an 8-byte {value, epoch} granule each and
+// gather all C of them, step after step, exactly as reducer_section (gpfq_loop_kernels.h) does -- without any sweep.
+// Prints microseconds per step by members, placement (members of a tile spread over the XCDs / on one XCD), variant of
+// the store / load pair and length of the pause that stands in for the sweep.
+//   hipcc --offload-arch=gfx950 -O3 -o xchg_probe xchg_probe.hip && ./xchg_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+// VARIANT 0: relaxed agent-scope atomic store / load (global_store_dwordx2 sc1, global_load_dwordx2 sc1) -- the product
+//         1: system scope (sc0 sc1)
+//         2: publish with an atomic exchange, poll with an atomic fetch-add of 0 (both executed at the coherence point)
+//         3: store as 0, poll with fetch-add 0
+//         4: store as 0, poll with global_load_dwordx2 sc0 -- STALE for ever: workgroup scope, a hit in the CU's own vector
+//            cache satisfies it
+//         6: store as 0, poll = buffer_inv sc1 + plain load
+//         7: store as 0, poll = buffer_inv sc0 + plain load
+//         8: plain store, poll = buffer_inv sc0 + plain load
+template <int VARIANT>
+__device__ __forceinline__ void publish(unsigned long long* p, unsigned long long v)
+{
+    if (VARIANT == 8) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory"); return; }
+    if (VARIANT == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (VARIANT == 2) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int VARIANT>
+__device__ __forceinline__ unsigned long long peek(unsigned long long* p)
+{
+    if (VARIANT == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (VARIANT >= 4) {
+        unsigned long long r;
+        if (VARIANT == 4) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+        else if (VARIANT == 6) asm volatile("buffer_inv sc1\n\tglobal_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+        else asm volatile("buffer_inv sc0\n\tglobal_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+        return r;
+    }
+    if (VARIANT >= 2) return __hip_atomic_fetch_add(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int VARIANT>
+__global__ void __launch_bounds__(64) xchg(unsigned long long* xb, int C, int steps, int one_xcd, int work, int first_pause,
+                                           unsigned* bad, float* sink)
+{
+    const int wg = blockIdx.x, lane = threadIdx.x;
+    const int tiles = gridDim.x / C;
+    int tile, c;
+    if (!one_xcd) { tile = wg / C; c = wg % C; }            // consecutive workgroup ids = round robin over the 8 XCDs
+    else { const int xcd = wg & 7, slot = wg >> 3; tile = xcd * (tiles >> 3) + slot / C; c = slot % C; }
+    unsigned long long* base = xb + (size_t)tile * 2 * C;
+    const int per = (C + 63) >> 6;                           // granules per lane
+    float acc = 0.0f;
+    bool dead = false;
+    for (int t = 0; t < steps; ++t) {
+        const unsigned epoch = (unsigned)t + 1u;
+        unsigned long long* xb_ = base + (size_t)(t & 1) * C;
+        for (int i = 0; i < work; ++i) __builtin_amdgcn_s_sleep(16);
+        if (lane == 0) publish<VARIANT>(xb_ + c, ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
+        for (int i = 0; i < first_pause; ++i) __builtin_amdgcn_s_sleep(4);
+        unsigned spins = dead ? (1u << 13) : 0u;
+        float v = 0.0f;
+        for (;;) {
+            unsigned long long ok = ~0ull;
+            v = 0.0f;
+            for (int i = 0; i < per; ++i) {
+                const int g = i * 64 + lane;
+                const bool want = g < C;
+                const unsigned long long gv = peek<VARIANT>(xb_ + (want ? g : 0));
+                ok &= __builtin_amdgcn_ballot_w64(!want || (unsigned)(gv >> 32) == epoch);
+                v += want ? __uint_as_float((unsigned)gv) : 0.0f;
+            }
+            if (ok == __builtin_amdgcn_read_exec()) break;
+            if (++spins > (1u << 13)) { dead = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        acc += v;
+    }
+    if (dead && lane == 0) atomicExch(bad, 1u);
+    if (lane == 0) sink[wg] = acc;
+}
+
+template <int VARIANT>
+static float run(unsigned long long* xb, unsigned* bad, float* sink, int C, int steps, int one_xcd, int work, int pause)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(xb, 0, 256 * 2 * sizeof(unsigned long long) * 2));
+        CK(hipEventRecord(a));
+        xchg<VARIANT><<<256, 64>>>(xb, C, steps, one_xcd, work, pause, bad, sink);
+        CK(hipEventRecord(b));
+        CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    unsigned h = 0; CK(hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost));
+    if (h) { CK(hipMemset(bad, 0, 4)); return -1.0f; }       // stale for ever: printed as -1
+    return best * 1000.0f / steps;
+}
+
+int main()
+{
+    unsigned long long* xb; unsigned* bad; float* sink;
+    CK(hipMalloc(&xb, 256 * 2 * sizeof(unsigned long long) * 2)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&sink, 256 * 4));
+    CK(hipMemset(bad, 0, 4));
+    const int steps = 4000;
+    for (int work = 0; work <= 2; work += 2) {
+        const float base0 = run<0>(xb, bad, sink, 1, steps, 0, work, 0);
+        printf("pause standing in for the sweep: %d x s_sleep 16; a step without partners (C = 1): %.3f us   (-1: stale for ever)\n", work, base0);
+        printf("%-8s %-10s %9s %9s %11s %11s %11s\n", "members", "placement", "sc1", "xchg/add0", "inv sc1+ld", "inv sc0+ld", "st,inv0+ld");
+        for (int C = 2; C <= 256; C <<= 1) {
+            for (int one = 0; one <= 1; ++one) {
+                if (one && C > 32) continue;
+                printf("%-8d %-10s %9.3f %9.3f %11.3f %11.3f %11.3f\n", C, one ? "one XCD" : "spread", run<0>(xb, bad, sink, C, steps, one, work, 0),
+                       run<2>(xb, bad, sink, C, steps, one, work, 0), run<6>(xb, bad, sink, C, steps, one, work, 0),
+                       run<7>(xb, bad, sink, C, steps, one, work, 0), run<8>(xb, bad, sink, C, steps, one, work, 0));
+                fflush(stdout);
+            }
+        }
+    }
+    // the first poll of an exchange after n x s_sleep 4 (256 clocks each): a poll that comes back incomplete costs a round trip
+    printf("first poll after n x s_sleep 4 (sc1 store / load, sweep stand-in 2 x s_sleep 16)\n%-8s %-10s", "members", "placement");
+    const int ns[] = {0, 1, 2, 3, 4, 6, 8, 12, 16};
+    for (int n : ns) printf(" %7d", n);
+    printf("\n");
+    for (int C = 8; C <= 256; C <<= 1) {
+        for (int one = 0; one <= 1; ++one) {
+            if (one && C > 32) continue;
+            printf("%-8d %-10s", C, one ? "one XCD" : "spread");
+            for (int n : ns) printf(" %7.3f", run<0>(xb, bad, sink, C, steps, one, 2, n));
+            printf("\n");
+            fflush(stdout);
+        }
+    }
+    return 0;
+}
