@@ -700,16 +700,26 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
             v2f acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f};
             const v2f qq01 = {qprev[0], qprev[1]}, ww01 = {wcur[0], wcur[1]};
             const v2f qq23 = {qprev[2], qprev[3]}, ww23 = {wcur[2], wcur[3]};
+            // the LDS reads of quarter q + 1 are issued before the arithmetic of quarter q (two quarters' 24 registers of
+            // columns at a time; the budget is 64)
+            float4 x4 = *reinterpret_cast<const float4*>(xc + 4 * lane);
+            float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * lane);
+            float4 p4 = *reinterpret_cast<const float4*>(xp + 4 * lane);
             auto quarter = [&](auto c_) {
                 constexpr int cq = decltype(c_)::value;
-                const float4 x4 = *reinterpret_cast<const float4*>(xc + 256 * cq + 4 * lane);
-                const float4 a4 = *reinterpret_cast<const float4*>(ab + 256 * cq + 4 * lane);
-                const float4 p4 = *reinterpret_cast<const float4*>(xp + 256 * cq + 4 * lane);
+                float4 nx = x4, na = a4, np = p4;
+                if constexpr (cq < 3) {
+                    nx = *reinterpret_cast<const float4*>(xc + 256 * (cq + 1) + 4 * lane);
+                    na = *reinterpret_cast<const float4*>(ab + 256 * (cq + 1) + 4 * lane);
+                    np = *reinterpret_cast<const float4*>(xp + 256 * (cq + 1) + 4 * lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 const v2f x01 = {x4.x, x4.y}, x23 = {x4.z, x4.w}, a01 = {a4.x, a4.y}, a23 = {a4.z, a4.w};
                 const v2f p01 = {p4.x, p4.y}, p23 = {p4.z, p4.w};
                 win_sweep4_pair_lds<U0 + 8 * cq>(acc01, qq01, ww01, p01, p23, a01, a23, x01, x23);
                 win_sweep4_pair_lds<U0 + 32 + 8 * cq>(acc23, qq23, ww23, p01, p23, a01, a23, x01, x23);
-                __builtin_amdgcn_sched_barrier(0);  // one quarter's twelve registers of columns at a time (the budget is 64)
+                __builtin_amdgcn_sched_barrier(0);
+                x4 = nx; a4 = na; p4 = np;
             };
             quarter(std::integral_constant<int, 0>{});
             quarter(std::integral_constant<int, 1>{});
@@ -725,7 +735,14 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
             dma(cols + (par ^ 1) * 1024, xg);
             dma(cols + 2048, ag);
         }
-        __syncthreads();
+        // Not __syncthreads(): its release fence waits for the LDS-DMA just issued (s_waitcnt vmcnt(0): the DMA writes
+        // LDS), and the columns would land BEFORE the exchange instead of under it -- 785-segment rows 80.2 -> 71.8 us per
+        // column, 197 segments 52.9 -> 50.2 (in-kernel stamps: the last sweep wave reaches the barrier 4 700 cycles into
+        // the step and then waited 1 900 more for its own columns).  The buffers they land in are this wave's own, and
+        // the wave waits for them itself at the top of its next sweep; what the barrier has to order is the LDS word
+        // written above (and the reducer's q below): lgkmcnt.  (Issuing the DMA behind the barrier instead, so that the
+        // reducer's granule goes first: 91.7 and 59.8.)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         float wn[RT];
         const int tn = more ? t + 1 : t;
 #pragma unroll
@@ -734,7 +751,7 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
         if (wave == rwave)
             gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
                                                                                 n2cur, in2cur, row0, grow0, seg_lo, gave_up);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
         if (!more) break;
