@@ -21,9 +21,9 @@ for a in sys.argv[1:]:
                                          compute_errors=False, step_override=step)
     torch.cuda.synchronize()
     scr = _lib.scratch(dev)
-    dbg = scr[96 * 1024 + 64: 96 * 1024 + 64 + 16 * 64].view(torch.int64).cpu().tolist()
+    dbg = scr[96 * 1024 + 64: 96 * 1024 + 64 + 32 * 64].view(torch.int64).cpu().tolist()
     print(a, _lib.describe_plan(N, d, m))
     print("  wave " + " ".join("%9s" % n for n in names[:7]) + "   arrives at barrier 1")
-    for w in range(16):
+    for w in list(range(14)) + list(range(16, 30)):
         v = [x / d for x in dbg[8 * w: 8 * w + 8]]
         print("  %4d " % w + " ".join("%9.0f" % x for x in v[:7]) + "   %9.0f" % sum(v[:4]))
