@@ -163,6 +163,8 @@ def kernel_name(desc, mode=0):
             return "gpfq_coop_rt1_m%d_w%d" % (mode, 16 if (waves > 12 or int(kv.get("C", "0")) > 128) else 12)
         if rt == 4 and waves > 12:                  # columns staged through LDS; 256 granules are gathered in fours
             return "gpfq_coop_rt4_m%d_w16l%s" % (mode, "q" if 4 * int(kv.get("C", "0")) > 128 else "")
+        if rt == 2 and int(kv.get("C", "0")) > 64:  # two rows on 256 members: 512 granules, gathered in eights
+            return "gpfq_coop_rt2_m%d_w16o" % mode
         return "gpfq_coop_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 16 if (rt == 2 and waves > 12) else 12)
     return "gpfq_stream_kernel<%d, true" % rt
 

@@ -175,13 +175,15 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullpt
     for (int RT = 4; RT >= 1; RT >>= 1) {
         if (force_rt && RT != force_rt) continue;
         const int64_t tiles = (Ng + RT - 1) / RT;
-        // the reducer gathers RT * C <= 128 granules (two per lane) -- 256 in the one-row 16-wave variant (four per lane)
-        for (int C = (RT == 1 ? 256 : (RT == 4 ? 64 : 128 / RT)); C >= 2; C >>= 1) {
+        // the reducer gathers RT * C <= 128 granules (two per lane) -- 256 in the one-row 16-wave variant (four per lane),
+        // 512 in the two-row one (eight per lane)
+        for (int C = (RT == 4 ? 64 : 256); C >= 2; C >>= 1) {
             if (force_c && C != force_c) continue;
             if (C > S || C > capacity) continue;
             const int NW = (S + C - 1) / C;
             if (RT == 1 && (C > 128 || NW > 12) && (C < 4 || NW > 15)) continue;   // (that variant gathers in fours)
             if (RT == 4 && C == 64 && NW != 13) continue;                          // (256 granules: the LDS-staged variant only)
+            if (RT == 2 && C > 64 && (C != 256 || NW <= 12 || NW > 15)) continue;  // (512 granules: the 16-wave variant, reducer wave of its own)
             if (RT == 4 && NW == 13 && env_int("GPFQ_COOP_NO_LDS", 0)) continue;
             if (NW > slab_max_waves(true, RT) || pow2_ceil_host(S) / C > 16) continue;
             const int64_t tiles_round = tiles * C <= capacity ? tiles : capacity / C;
@@ -435,6 +437,17 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
     return nullptr;
 }
 
+// two rows on 256 members, eight granules gathered per lane
+SlabKernel coop_kernel_oct(int mode)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return gpfq::gpfq_coop_rt2_m1_w16o;
+    case gpfq::MODE_HARD: return gpfq::gpfq_coop_rt2_m2_w16o;
+    case gpfq::MODE_STOCHASTIC: return nullptr;     // (see GPFQ_DEFINE_COOP_OCT in gpfq_loop_kernels.h)
+    default: return gpfq::gpfq_coop_rt2_m0_w16o;
+    }
+}
+
 // four rows at 13 sweep waves, columns staged through LDS (gpfq_loop_kernels.h coop_lds_body)
 SlabKernel coop_kernel_lds(int mode, bool quad)
 {
@@ -462,7 +475,8 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     const int RT = pl.RT;
     const int maxw = pl.grouped ? 12 : coop_wave_bound(RT, pl.waves, pl.C);
     const bool lds = RT == 4 && maxw == 16 && !pl.grouped;
-    SlabKernel kern = pl.grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * pl.C > 128) : coop_kernel(RT, mode, maxw);
+    const bool oct = RT == 2 && pl.C == 256 && maxw == 16 && !pl.grouped;
+    SlabKernel kern = pl.grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * pl.C > 128) : oct ? coop_kernel_oct(mode) : coop_kernel(RT, mode, maxw);
     if (!kern || pl.waves > maxw || (lds && pl.waves != 13))
         return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
     // one more wave for the reducer role when the variant's wave bound allows it

@@ -123,7 +123,8 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 // ABORTWORD: the old protocol, kept for the four-row 12-wave variant only (no register left for the `gave_up` state):
 // the reducer leaves the fact in a word of qs and every wave tests it behind barrier 2 and leaves the loop.
 // QUAD: the one-row 16-wave variant gathers FOUR members per lane (4j .. 4j+3: two levels of the tree over the members in
-// the lane), so that up to 256 members -- a whole chip for one row of up to 4096 segments -- fit the 64 lanes.
+// the lane), so that up to 256 members -- a whole chip for one row of up to 4096 segments -- fit the 64 lanes.  With two
+// rows (256 members x 2 rows = 512 granules) a lane gathers EIGHT members, 8j .. 8j+7, three levels in the lane.
 template <int RT, int MODE, bool FAST, bool ABORTWORD, bool QUAD = false>
 __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int lane, int tile, int c, int C, int par,
@@ -141,9 +142,10 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
     // Gather layout: lane = stride * row + member.  More than 64 granules (RT * C <= 128: long rows that run in rounds)
     // are gathered two members per lane, 2j and 2j+1 -- adjacent member blocks, the pair the first level of the tree
     // over the members adds anyway.
-    static_assert(!QUAD || RT == 1 || RT == 4, "four members per lane: the one-row and the LDS-staged four-row variants");
+    static_assert(!QUAD || RT == 1 || RT == 2 || RT == 4, "four (two rows: eight) members per lane");
+    constexpr int G = RT == 2 ? 8 : 4;       // QUAD: members per lane
     const bool wide = !QUAD && RT * C > 64;
-    const int per_row = QUAD ? C >> 2 : (wide ? C >> 1 : C);  // lanes per row
+    const int per_row = QUAD ? C / G : (wide ? C >> 1 : C);  // lanes per row
     const int sh = per_row <= 16 ? 4 : (per_row <= 32 ? 5 : 6);   // log2 of the lane stride of a row in the gather
     const int gr_ = lane >> sh;              // row of this lane
     const int member = lane & ((1 << sh) - 1);
@@ -156,7 +158,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                                ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool want = member < per_row && gr_ < RT;
-        const unsigned long long* src = xb_ + (want ? (size_t)(QUAD ? 4 * member : (wide ? 2 * member : member)) * RT + gr_ : 0);
+        const unsigned long long* src = xb_ + (want ? (size_t)(QUAD ? G * member : (wide ? 2 * member : member)) * RT + gr_ : 0);
         unsigned long long gv = 0, gw = 0;
         // once an exchange of this launch has timed out (status raised, the host redoes the layer) the later ones give up
         // at their first unanswered poll: the launch runs to its end on whatever q comes out, nobody needs an exit path
@@ -174,20 +176,29 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         // + 2.6 % on layer3.0.conv2.)
         if (p.spin_limit & 1u) __builtin_amdgcn_s_sleep(8);
         if constexpr (QUAD) {
+            // (eight members per lane: two batches of four loads, each summed as soon as it has been checked -- sixteen
+            // registers of granules in flight do not fit beside two residual rows and the column window)
             unsigned long long g[4];
+            float v4 = 0.0f;
             for (;;) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) g[i] = __hip_atomic_load(src + (want ? i * RT : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned long long ok = ~0ull;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64((unsigned)(g[i] >> 32) == epoch);
+                for (int b = 0; b < G / 4; ++b) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        g[i] = __hip_atomic_load(src + (4 * b + i) * RT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (idle lanes: granules 0 .. G-1, in bounds: C >= G)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64((unsigned)(g[i] >> 32) == epoch);
+                    const float vb = (__uint_as_float((unsigned)g[0]) + __uint_as_float((unsigned)g[1])) +
+                                     (__uint_as_float((unsigned)g[2]) + __uint_as_float((unsigned)g[3]));
+                    v4 = b == 0 ? vb : v4 + vb;
+                    if constexpr (G == 8) __builtin_amdgcn_sched_barrier(0);
+                }
                 if ((ok | idle) == __builtin_amdgcn_read_exec()) break;
                 if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            v = want ? (__uint_as_float((unsigned)g[0]) + __uint_as_float((unsigned)g[1])) +
-                           (__uint_as_float((unsigned)g[2]) + __uint_as_float((unsigned)g[3]))
-                     : 0.0f;
+            v = want ? v4 : 0.0f;
         } else if (!wide) {
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -825,6 +836,19 @@ GPFQ_DEFINE_COOP_MODES(2, 16, 1, 48, "v127")
         coop_body<1, MODE, 1, 64, true>(p);                                                                       \
     }
 GPFQ_DEFINE_COOP_QUAD(0) GPFQ_DEFINE_COOP_QUAD(1) GPFQ_DEFINE_COOP_QUAD(2) GPFQ_DEFINE_COOP_QUAD(3)
+// two rows on up to 256 members (512 granules, eight gathered per lane): rows so long that one row alone takes the whole
+// chip (EfficientNet-B1's 112 x 112 maps at batch 1024, 3137 segments) pull every column from HBM once per ROW TILE, and
+// that traffic, not the exchange, is what their step waits for
+#define GPFQ_DEFINE_COOP_OCT(MODE)                                                                                \
+    __global__ void __launch_bounds__(64 * 16) __attribute__((amdgpu_num_vgpr(48 / 2)))                            \
+    gpfq_coop_rt2_m##MODE##_w16o(const SlabParams p)                                                              \
+    {                                                                                                             \
+        asm volatile("" ::: "v127");                                                                              \
+        coop_body<2, MODE, 1, 48, true>(p);                                                                       \
+    }
+// (no stochastic variant: with the Philox rounds four registers would spill; the host streams that combination, as for the
+// four-row 12-wave kernel)
+GPFQ_DEFINE_COOP_OCT(0) GPFQ_DEFINE_COOP_OCT(1) GPFQ_DEFINE_COOP_OCT(2)
 // one row per group (depthwise convolutions with long rows), 12 waves: the one-row variant with per-row columns
 #define GPFQ_DEFINE_COOP_GROUPED(MODE)                                                                            \
     __global__ void __launch_bounds__(64 * 12) __attribute__((amdgpu_num_vgpr(72 / 2)))                            \

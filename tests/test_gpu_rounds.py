@@ -41,8 +41,10 @@ CASES = [
     ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
     ((12, 6, 1440768), {}, "coop RT=1 C=128 waves=11 S=1407 grid=256 rounds=6",
      "128 members of one row (EfficientNet-B1's first conv at batch 1024): 64 lanes x 2 granules, two rows per round"),
-    ((3, 4, 3212288), {}, "coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=3",
+    ((3, 4, 3212288), {"GPFQ_COOP_RT": "1"}, "coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=3",
      "one row on the whole chip (EfficientNet-B1's 112 x 112 maps): 256 members, four gathered per lane, 13 sweep waves"),
+    ((5, 4, 3212288), {}, "coop RT=2 C=256 waves=13 S=3137 grid=256 rounds=3",
+     "two rows on the whole chip: 512 granules, eight gathered per lane in two batches; the last tile has one valid row"),
     ((5, 4, 300000), {"GPFQ_COOP_RT": "1", "GPFQ_COOP_C": "256", "plan": "3"}, "coop RT=1 C=256 waves=2 S=293 grid=256 rounds=5",
      "the same variant with two sweep waves per member and an idle upper half of the slot tree (293 of 512 slots)"),
 ]
@@ -77,7 +79,7 @@ def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, mode):
     draws: equality with the oracle (keyed by global rows) and with the streaming plan shows it."""
     from quantized_neural_nets_amd import _lib
     omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
-    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200)):
+    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (3, 3, 3212288)):   # (the last: two rows x 256 members; stochastic streams)
         assert "rounds=" in _lib.describe_plan(N, d, m)
         W, A, X = bw.synthetic_layer(N, d, m, 91 + N, first_layer=False)
         step = bw.layer_step(W)

@@ -79,7 +79,8 @@ def test_plan_selection(lib):
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=16 waves=13 S=197 grid=256 rounds=16")
     assert lib.describe_plan(256, 64, 803840).startswith("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16")    # 256 granules
     assert lib.describe_plan(2048, 512, 13312).startswith("resident RT=1 waves=13")     # <= 16 segments: whole rows, no exchange
-    assert lib.describe_plan(16, 32, 3212288).startswith("coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=16")   # one row on the whole chip
+    assert lib.describe_plan(16, 32, 3212288).startswith("coop RT=2 C=256 waves=13 S=3137 grid=256 rounds=8")    # two rows on the whole chip
+    assert lib.describe_plan(1, 32, 3212288).startswith("coop RT=1 C=256 waves=13 S=3137 grid=256 d=32")         # one row on the whole chip
     assert lib.describe_plan(4, 8, 4194304).startswith("stream")                        # 4096 segments: beyond 256 members x 15
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
     # the fallback plan: whole rows per workgroup, never an exchange, whatever the shape
@@ -258,6 +259,7 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert bench.kernel_name("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32 d=64") == "gpfq_coop_rt2_m0_w16"
     assert bench.kernel_name("coop RT=4 C=32 waves=9 S=257 grid=256 rounds=2 d=147") == "gpfq_coop_rt4_m0_w12"
     assert bench.kernel_name("coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=16 d=32", 1) == "gpfq_coop_rt1_m1_w16"
+    assert bench.kernel_name("coop RT=2 C=256 waves=13 S=3137 grid=256 rounds=8 d=32", 1) == "gpfq_coop_rt2_m1_w16o"
     assert bench.kernel_name("coop RT=4 C=4 waves=13 S=50 grid=256 rounds=8 d=1024") == "gpfq_coop_rt4_m0_w16l"
     assert bench.kernel_name("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16 d=64", 1) == "gpfq_coop_rt4_m1_w16lq"
     assert bench.kernel_name("coop RT=1 C=16 waves=6 S=91 grid=128 d=576") == "gpfq_coop_rt1_m0_w12"
