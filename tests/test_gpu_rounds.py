@@ -37,7 +37,11 @@ CASES = [
     ((70, 16, 201728), {}, "coop RT=4 C=16 waves=13 S=197 grid=256 rounds=2", "the same variant with 16 members (64 granules)"),
     ((21, 10, 803840), {}, "coop RT=4 C=64 waves=13 S=785 grid=256 rounds=2",
      "the same variant with 64 members: 256 granules gathered four per lane; 16 rows per round, 5 in the last"),
-    ((20, 10, 720384), {}, "coop RT=2 C=64 waves=11 S=704 grid=256 rounds=3", "128 granules at 64 members (VGG-16 conv1 rows)"),
+    ((20, 10, 720384), {"GPFQ_COOP_RT": "2"}, "coop RT=2 C=64 waves=11 S=704 grid=256 rounds=3", "128 granules at 64 members (VGG-16 conv1 rows)"),
+    ((20, 10, 720384), {}, "coop RT=4 C=64 waves=11 S=704 grid=256 rounds=2",
+     "the LDS-staged 64-member kernel with fewer than 13 sweep waves (VGG-16 conv1 rows: 11 segments per member)"),
+    ((9, 6, 530000), {}, "coop RT=4 C=64 waves=9 S=518 grid=192",
+     "the same with 9 sweep waves, members of 8 and 9 segments, one round with a partial last tile"),
     ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
     ((12, 6, 1440768), {}, "coop RT=1 C=128 waves=11 S=1407 grid=256 rounds=6",
      "128 members of one row (EfficientNet-B1's first conv at batch 1024): 64 lanes x 2 granules, two rows per round"),
