@@ -81,6 +81,7 @@ int coop_wave_bound(int RT, int NW, int C)
 {
     if (RT == 1) return (NW <= 12 && C <= 128) ? 12 : 16;    // (16: the variant that gathers four members per lane)
     if (RT == 4 && C == 64) return 16;                  // (256 granules: the LDS-staged variant only, up to 13 sweep waves)
+    if (RT == 2 && C > 64) return 16;                   // (the variant that gathers eight members per lane)
     if (NW <= 8) return 8;
     if (RT == 4) return NW <= 12 ? 12 : 16;             // (16: the LDS-staged variant, 13 sweep waves)
     return NW <= 12 ? 12 : 16;
@@ -184,7 +185,7 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullpt
             const int NW = (S + C - 1) / C;
             if (RT == 1 && (C > 128 || NW > 12) && (C < 4 || NW > 15)) continue;   // (that variant gathers in fours)
             if (RT == 4 && C == 64 && NW > 13) continue;                           // (256 granules: the LDS-staged variant only)
-            if (RT == 2 && C > 64 && (C != 256 || NW <= 12 || NW > 15)) continue;  // (512 granules: the 16-wave variant, reducer wave of its own)
+            if (RT == 2 && C > 64 && NW > 15) continue;                            // (256 / 512 granules: the 16-wave variant that gathers eight members per lane, reducer wave of its own)
             if (RT == 4 && NW == 13 && env_int("GPFQ_COOP_NO_LDS", 0)) continue;
             if (NW > slab_max_waves(true, RT) || pow2_ceil_host(S) / C > 16) continue;
             const int64_t tiles_round = tiles * C <= capacity ? tiles : capacity / C;
@@ -476,7 +477,7 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     const int RT = pl.RT;
     const int maxw = pl.grouped ? 12 : coop_wave_bound(RT, pl.waves, pl.C);
     const bool lds = RT == 4 && maxw == 16 && !pl.grouped;
-    const bool oct = RT == 2 && pl.C == 256 && maxw == 16 && !pl.grouped;
+    const bool oct = RT == 2 && pl.C > 64 && maxw == 16 && !pl.grouped;
     SlabKernel kern = pl.grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * pl.C > 128) : oct ? coop_kernel_oct(mode) : coop_kernel(RT, mode, maxw);
     if (!kern || pl.waves > maxw || (lds && pl.waves > 13))
         return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");

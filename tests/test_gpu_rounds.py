@@ -43,7 +43,11 @@ CASES = [
     ((9, 6, 530000), {}, "coop RT=4 C=64 waves=9 S=518 grid=192",
      "the same with 9 sweep waves, members of 8 and 9 segments, one round with a partial last tile"),
     ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
-    ((12, 6, 1440768), {}, "coop RT=1 C=128 waves=11 S=1407 grid=256 rounds=6",
+    ((12, 6, 1440768), {}, "coop RT=2 C=128 waves=11 S=1407 grid=256 rounds=3",
+     "two rows on 128 members with 11 sweep waves: 256 granules, eight gathered per lane in 16 lanes per row"),
+    ((3, 4, 1000000), {}, "coop RT=2 C=128 waves=8 S=977 grid=256",
+     "the same kernel with 8 sweep waves, one round, the second tile with one valid row"),
+    ((12, 6, 1440768), {"GPFQ_COOP_RT": "1"}, "coop RT=1 C=128 waves=11 S=1407 grid=256 rounds=6",
      "128 members of one row (EfficientNet-B1's first conv at batch 1024): 64 lanes x 2 granules, two rows per round"),
     ((3, 4, 3212288), {"GPFQ_COOP_RT": "1"}, "coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=3",
      "one row on the whole chip (EfficientNet-B1's 112 x 112 maps): 256 members, four gathered per lane, 13 sweep waves"),
