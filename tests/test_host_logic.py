@@ -248,7 +248,9 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert got == 123 and src.endswith("r99_b_pmc_traffic.json")
     # and the committed summary of this round matches the committed sources, kernel names included
     import glob
-    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]
+    import re
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")),       # (r02_v10 after r02_v9)
+                    key=lambda f: [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(f))])[-1]
     real = json.load(open(newest))
     assert real["source_sha256"] == digest, "%s was collected on other kernel sources: re-collect (tools/profile_bench.sh)" % newest
     assert any("gpfq_resident_rt2_m0_w8" in k for k in real["kernels"]) and any("gpfq_coop_rt4_m0_w12" in k for k in real["kernels"])
