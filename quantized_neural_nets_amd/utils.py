@@ -101,3 +101,20 @@ def test_accuracy(model, test_dl, device, topk=(1, )):
 
 
 test_accuracy.__test__ = False      # not a pytest test
+
+
+def parse_imagenet_val_labels(data_dir):
+    '''Class labels of the ILSVRC2012 validation images in file order (utils.py:28-51; the reference's
+    data_loaders.py:12 imports this name from `utils`).  Reads the devkit's meta.mat (leaf synsets: ILSVRC id -> wnid),
+    ILSVRC2012_validation_ground_truth.txt (one ILSVRC id per image) and wnid_to_label.pickle (wnid -> class index).'''
+    import os
+    import pickle
+
+    import numpy as np
+    import scipy.io as sio
+    synsets = sio.loadmat(os.path.join(data_dir, 'meta.mat'), squeeze_me=True)['synsets']
+    wnid_of = {int(s[0]): str(s[1]) for s in synsets if int(s[4]) == 0}          # leaves only (num_children == 0)
+    truth = np.loadtxt(os.path.join(data_dir, 'ILSVRC2012_validation_ground_truth.txt'))
+    with open(os.path.join(data_dir, 'wnid_to_label.pickle'), 'rb') as f:
+        label_of = pickle.load(f)
+    return np.array([label_of[wnid_of[int(i)]] for i in truth])
