@@ -189,8 +189,14 @@ int gpfq_gather_patches_f32(const float* x, int64_t B, int64_t C, int64_t H, int
  */
 int gpfq_row_absmax_f32(const float* W, int64_t ldw, int64_t N, int64_t d, float* rowmax, void* stream);
 
-/* Writes a one-line description of the plan AUTO would pick; returns the plan id or a negative error. */
+/* Writes a one-line description of the plan `plan` resolves to for this shape (GPFQ_PLAN_AUTO: the plan AUTO would
+ * pick) with the quantizer GPFQ_MODE_MSQ; returns the plan id or a negative error. */
 int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, char* buf, size_t buf_bytes);
+/* The same for a given quantizer: the plan depends on `mode` where a kernel variant is not instantiated for every
+ * quantizer (two cooperative variants have no GPFQ_MODE_STOCHASTIC form), so that the description is always the
+ * plan that launches. */
+int gpfq_describe_plan_mode(int64_t N, int64_t d_g, int64_t m, int groups, int plan, int mode, char* buf,
+                            size_t buf_bytes);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@ library binds to; streams and device pointers are then shared with torch.
 import ctypes
 import os
 import subprocess
+import threading
 
 import torch  # noqa: F401  (must precede loading the library, see above)
 
@@ -21,6 +22,7 @@ EXPORTS = [
     "gpfq_prepare_columns_f32", "gpfq_quantization_f32", "gpfq_quantize_layer_f32", "gpfq_quantizer_f32",
     "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32", "gpfq_scratch_bytes",
     "gpfq_read_status", "gpfq_column_norms_f32", "gpfq_gather_patches_f32", "gpfq_last_launch_used_exchange",
+    "gpfq_describe_plan_mode",
 ]
 
 
@@ -77,6 +79,8 @@ def _load():
     lib.gpfq_row_absmax_f32.argtypes = [vp, i64, i64, i64, vp, vp]
     lib.gpfq_describe_plan.restype = i32
     lib.gpfq_describe_plan.argtypes = [i64, i64, i64, i32, i32, c.c_char_p, sz]
+    lib.gpfq_describe_plan_mode.restype = i32
+    lib.gpfq_describe_plan_mode.argtypes = [i64, i64, i64, i32, i32, i32, c.c_char_p, sz]
     if lib.gpfq_abi_version() != 3:
         raise ImportError("libgpfq_hip.so ABI version mismatch")
     return lib
@@ -104,19 +108,29 @@ def current_stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-_scratch = {}
+_scratch = {}           # device index -> scratch buffer
+_scratch_user = {}      # device index -> the stream whose launches used the scratch last
+_scratch_lock = threading.Lock()
 
 
 def scratch(device):
-    """Scratch area of the cooperative plans (exchange granules + status words), one per (device, stream): launches on
-    one stream are serialised by the stream, and two streams never share granules.  Allocated and zeroed once."""
+    """Scratch area of the cooperative plans (exchange granules + status words), ONE PER DEVICE, allocated and zeroed
+    once.  A cooperative grid is sized to be co-resident on an otherwise idle chip (a plain launch behind an occupancy
+    query), so two of them running at once on two streams would each be only partly resident and spin to their
+    bounds: launches that use the scratch are therefore serialised per device -- a caller on another stream than the
+    previous user's first waits (on the device, not the host) for everything that stream has queued."""
     dev = torch.device(device)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
-    key = (index, torch.cuda.current_stream(index).cuda_stream)
-    buf = _scratch.get(key)
-    if buf is None:
-        buf = torch.zeros((lib.gpfq_scratch_bytes(),), dtype=torch.uint8, device=torch.device("cuda", index))
-        _scratch[key] = buf
+    cur = torch.cuda.current_stream(index)
+    with _scratch_lock:
+        buf = _scratch.get(index)
+        if buf is None:
+            buf = torch.zeros((lib.gpfq_scratch_bytes(),), dtype=torch.uint8, device=torch.device("cuda", index))
+            _scratch[index] = buf
+        last = _scratch_user.get(index)
+        if last is not None and last.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(last)
+        _scratch_user[index] = cur
     return buf
 
 
@@ -144,9 +158,10 @@ def check_status(device):
             rc, lib.gpfq_last_error().decode(), st[1], st[2], st[3]))
 
 
-def describe_plan(N, d_g, m, groups=1, plan=PLAN_AUTO):
+def describe_plan(N, d_g, m, groups=1, plan=PLAN_AUTO, mode=MODE_MSQ):
+    """One-line description of the plan that launches for this shape and quantizer (include/gpfq.h)."""
     buf = ctypes.create_string_buffer(256)
-    rc = lib.gpfq_describe_plan(N, d_g, m, groups, plan, buf, 256)
+    rc = lib.gpfq_describe_plan_mode(N, d_g, m, groups, plan, mode, buf, 256)
     if rc < 0:
         check(rc)
     return buf.value.decode()

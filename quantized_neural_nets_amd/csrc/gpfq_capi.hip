@@ -40,6 +40,11 @@ int hip_fail(hipError_t e, const char* what)
 constexpr int kMaxResidentSegments = 16;
 constexpr size_t kScratchBytes = 128 * 1024;        // [0, 96 KiB) exchange granules, [96 KiB, ...) status words
 constexpr size_t kScratchStatusOffset = 96 * 1024;
+// Polls before an exchange gives up.  A poll is one sc1 load round trip (0.65-0.85 us, profiles/r02_xchg_probe.txt) plus
+// a 64-clock pause, and an exchange of a co-resident grid completes within a handful of them; 2^14 polls are ~12 ms, so a
+// grid whose co-residency broke (another process on the card) costs milliseconds before the layer is redone on the
+// whole-row streaming plan -- not the ~1.5 s of the former 2^21.
+constexpr int kDefaultSpinLimit = 1 << 14;
 
 struct Plan {
     int kind;      // GPFQ_PLAN_STREAM / GPFQ_PLAN_RESIDENT / GPFQ_PLAN_COOP
@@ -74,6 +79,11 @@ int env_int(const char* name, int dflt)
 
 int slab_max_waves(bool coop, int RT);
 int resident_max_rt(int waves);
+
+// Is there an instantiation of the cooperative kernel for (rows per workgroup, sweep waves, members) with this
+// quantizer?  Answered by the same table the launch uses (coop_kernel_for, below), so that a pair without one is never
+// CHOSEN: the plan that is described is the plan that launches.  (Today every pair exists for all four quantizers.)
+bool coop_variant_exists(int RT, int NW, int C, int mode);
 
 // wave bound of the cooperative kernel variant that takes NW sweep waves of RT rows split over C members (keep
 // coop_kernel() in step)
@@ -166,7 +176,7 @@ double stream_col_cost(int64_t Ng, int S, int cus)
 // chip, one launch per block, every launch walking all d columns with its block of U in registers (the columns come
 // from L2 / the Infinity Cache again; U, the 8*N*m bytes per column of the streaming plan, never moves).
 // Depends on (Ng, S, CU count) only -- never on the data.  cost_out: microseconds per column for all rows.
-bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullptr, bool allow_rounds = true)
+bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out = nullptr, bool allow_rounds = true)
 {
     const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
     const int wgs_per_cu = env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1;
@@ -188,6 +198,7 @@ bool choose_coop(int64_t Ng, int S, int cus, Plan* pl, double* cost_out = nullpt
             if (RT == 2 && C > 64 && NW > 15) continue;                            // (256 / 512 granules: the 16-wave variant that gathers eight members per lane, reducer wave of its own)
             if (RT == 4 && NW == 13 && env_int("GPFQ_COOP_NO_LDS", 0)) continue;
             if (NW > slab_max_waves(true, RT) || pow2_ceil_host(S) / C > 16) continue;
+            if (!coop_variant_exists(RT, NW, C, mode)) continue;
             const int64_t tiles_round = tiles * C <= capacity ? tiles : capacity / C;
             const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
             if (rounds > 1 && !allow_rounds) continue;
@@ -286,7 +297,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
     }
 }
 
-int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, Plan* out)
+int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, int mode, Plan* out)
 {
     Plan pl;
     pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0; pl.grouped = 0;
@@ -310,7 +321,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
         if (requested == GPFQ_PLAN_AUTO && groups == 1 && have_scratch && Ng > cus && !env_int("GPFQ_COOP_DISABLE", 0)) {
             Plan cp = pl;
             double ccost = 0.0;
-            if (choose_coop(Ng, pl.S, cus, &cp, &ccost, false) && ccost < 0.97 * resident_step_cost(Ng, pl.S, cus)) {
+            if (choose_coop(Ng, pl.S, cus, mode, &cp, &ccost, false) && ccost < 0.97 * resident_step_cost(Ng, pl.S, cus)) {
                 *out = cp;
                 return GPFQ_OK;
             }
@@ -330,7 +341,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     }
     if (requested == GPFQ_PLAN_COOP || (requested == GPFQ_PLAN_AUTO && !env_int("GPFQ_COOP_DISABLE", 0))) {
         double ccost = 0.0;
-        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, &pl, &ccost)) {
+        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, mode, &pl, &ccost)) {
             // in rounds only where that beats moving U through memory every column
             if (pl.rounds == 1 || requested == GPFQ_PLAN_COOP || ccost < 0.9 * stream_col_cost(Ng, pl.S, cus)) {
                 *out = pl;
@@ -356,7 +367,7 @@ int launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool ve
     const size_t shm = sizeof(float) * (2 * RT * (size_t)n_max + 2 * (RT + 1));
     gpfq::StreamCoop sc;
     sc.C = C; sc.tiles = pl.tiles; sc.xbuf = nullptr; sc.status = nullptr;
-    sc.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21);
+    sc.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit);
     hipError_t e;
     if (C > 1) {
         const int nblocks = pl.tiles * C;
@@ -403,7 +414,7 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.inv_step = fast_ok ? 1.0f / p.qc.step : __builtin_nanf("");
     sp.msq_thr = 0.5f - (p.qc.Kf + 4.0f) * 0x1p-18f;
     // bit 0: pause before the first poll of an exchange (reducer_section: where 32 or more granules are awaited)
-    sp.spin_limit = 2u * (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", 1 << 21) +
+    sp.spin_limit = 2u * (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit) +
                     (env_int("GPFQ_COOP_POLL_DELAY", pl.RT * pl.C >= 32 ? 1 : 0) ? 1u : 0u);
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
     sp.xcd_tiles = 0;                               // launch_coop decides
@@ -425,18 +436,9 @@ SlabKernel coop_kernel(int RT, int mode, int maxw)
         default: return gpfq::gpfq_coop_rt##RTV##_m0_w##MAXWV;                                                        \
         }                                                                                                             \
     }
-    GPFQ_PICK(1, 12) GPFQ_PICK(1, 16) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(2, 16) GPFQ_PICK(4, 8)
+    GPFQ_PICK(1, 12) GPFQ_PICK(1, 16) GPFQ_PICK(2, 8) GPFQ_PICK(2, 12) GPFQ_PICK(2, 16) GPFQ_PICK(4, 8) GPFQ_PICK(4, 12)
 #undef GPFQ_PICK
-    if (RT == 4 && maxw == 16) return nullptr;      // (coop_kernel_lds)
-    if (RT == 4 && maxw == 12) {                    // (no stochastic variant: see GPFQ_DEFINE_COOP in gpfq_loop_kernels.h)
-        switch (mode) {
-        case gpfq::MODE_SOFT: return gpfq::gpfq_coop_rt4_m1_w12;
-        case gpfq::MODE_HARD: return gpfq::gpfq_coop_rt4_m2_w12;
-        case gpfq::MODE_MSQ: return gpfq::gpfq_coop_rt4_m0_w12;
-        default: return nullptr;
-        }
-    }
-    return nullptr;
+    return nullptr;                                 // (four rows at 16: coop_kernel_lds)
 }
 
 // two rows on 256 members, eight granules gathered per lane
@@ -445,7 +447,7 @@ SlabKernel coop_kernel_oct(int mode)
     switch (mode) {
     case gpfq::MODE_SOFT: return gpfq::gpfq_coop_rt2_m1_w16o;
     case gpfq::MODE_HARD: return gpfq::gpfq_coop_rt2_m2_w16o;
-    case gpfq::MODE_STOCHASTIC: return nullptr;     // (see GPFQ_DEFINE_COOP_OCT in gpfq_loop_kernels.h)
+    case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_coop_rt2_m3_w16o;
     default: return gpfq::gpfq_coop_rt2_m0_w16o;
     }
 }
@@ -472,14 +474,31 @@ SlabKernel coop_kernel_grouped(int mode)
     }
 }
 
+// The kernel a cooperative configuration launches (nullptr: no instantiation), its wave bound and whether it stages its
+// columns through LDS -- the ONE table behind launch_coop and coop_variant_exists.
+SlabKernel coop_kernel_for(int RT, int NW, int C, int mode, bool grouped, int* maxw_out, bool* lds_out)
+{
+    const int maxw = grouped ? 12 : coop_wave_bound(RT, NW, C);
+    const bool lds = RT == 4 && maxw == 16 && !grouped;
+    const bool oct = RT == 2 && C > 64 && maxw == 16 && !grouped;
+    if (maxw_out) *maxw_out = maxw;
+    if (lds_out) *lds_out = lds;
+    if (NW > maxw || (lds && NW > 13)) return nullptr;
+    return grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * C > 128) : oct ? coop_kernel_oct(mode) : coop_kernel(RT, mode, maxw);
+}
+
+bool coop_variant_exists(int RT, int NW, int C, int mode)
+{
+    return coop_kernel_for(RT, NW, C, mode, false, nullptr, nullptr) != nullptr;
+}
+
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
     const int RT = pl.RT;
-    const int maxw = pl.grouped ? 12 : coop_wave_bound(RT, pl.waves, pl.C);
-    const bool lds = RT == 4 && maxw == 16 && !pl.grouped;
-    const bool oct = RT == 2 && pl.C > 64 && maxw == 16 && !pl.grouped;
-    SlabKernel kern = pl.grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * pl.C > 128) : oct ? coop_kernel_oct(mode) : coop_kernel(RT, mode, maxw);
-    if (!kern || pl.waves > maxw || (lds && pl.waves > 13))
+    int maxw = 0;
+    bool lds = false;
+    SlabKernel kern = coop_kernel_for(RT, pl.waves, pl.C, mode, pl.grouped != 0, &maxw, &lds);
+    if (!kern)
         return fail(GPFQ_ERR_UNSUPPORTED, "internal: no cooperative kernel for this (rows, waves) pair");
     // one more wave for the reducer role when the variant's wave bound allows it
     const int nwaves = pl.waves + ((pl.waves + 1 <= maxw && !env_int("GPFQ_NO_REDUCER_WAVE", 0)) ? 1 : 0);
@@ -606,7 +625,7 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     if (p.u_has_init && plan == GPFQ_PLAN_AUTO) plan = GPFQ_PLAN_STREAM;
     if (p.u_has_init && plan != GPFQ_PLAN_STREAM && plan != GPFQ_PLAN_STREAM_ROWS)
         return fail(GPFQ_ERR_UNSUPPORTED, "an initial residual needs a streaming plan");
-    int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, &pl);
+    int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, p.qc.mode, &pl);
     if (rc) return rc;
     if (groups > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "groups > 65535");
     p.S = pl.S;
@@ -630,7 +649,7 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
         }
         if (rc == GPFQ_OK) g_used_exchange = 1;
         if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
-        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, &pl);   // does not fit: stream instead
+        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, p.qc.mode, &pl);   // does not fit: stream instead
         if (rc) return rc;
     }
     if (pl.kind == GPFQ_PLAN_COOP) {
@@ -655,7 +674,7 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
         }
         if (rc == GPFQ_OK) g_used_exchange = 1;
         if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
-        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, &pl);   // does not fit: stream instead
+        rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, p.qc.mode, &pl);   // does not fit: stream instead
         if (rc) return rc;
     }
     if (pl.kind == GPFQ_PLAN_RESIDENT) return launch_slab(pl, p, groups, vec, scratch, st);
@@ -904,9 +923,15 @@ int gpfq_row_absmax_f32(const float* W, int64_t ldw, int64_t N, int64_t d, float
 
 int gpfq_describe_plan(int64_t N, int64_t d_g, int64_t m, int groups, int plan, char* buf, size_t buf_bytes)
 {
+    return gpfq_describe_plan_mode(N, d_g, m, groups, plan, GPFQ_MODE_MSQ, buf, buf_bytes);
+}
+
+int gpfq_describe_plan_mode(int64_t N, int64_t d_g, int64_t m, int groups, int plan, int mode, char* buf, size_t buf_bytes)
+{
     if (groups < 1 || N % groups != 0) return fail(GPFQ_ERR_ARG, "bad groups");
+    if (mode < 0 || mode > 3) return fail(GPFQ_ERR_ARG, "mode must be 0..3");
     Plan pl;
-    int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, &pl);
+    int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, mode, &pl);
     if (rc) return rc;
     if (buf && buf_bytes) {
         if (pl.kind == GPFQ_PLAN_COOP && pl.grouped)

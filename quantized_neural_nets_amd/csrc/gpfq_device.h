@@ -588,6 +588,19 @@ __device__ __forceinline__ void win_read4_s2(float (&d)[4])
                  : "=v"(d[0]), "=v"(d[1]), "=v"(d[2]), "=v"(d[3]) : "n"(B));
 }
 
+// The lane number, recomputed where it is used and opaque to the compiler.  For the rare blocks of a kernel (the Q / idx
+// flush every 64 steps, the epilogue): everything they derive from the lane number -- per-lane 64-bit store addresses for
+// every row -- is then defined inside the block instead of being hoisted above the column loop and kept live across it
+// (24 VGPRs in the 64-register variants, which went to scratch), and the loop's own copy of the lane number need not
+// stay live for them either.  (v_mbcnt counts the bits of its MASK operand, here all ones, below the lane: the lane's
+// position, whatever EXEC is.)
+__device__ __forceinline__ int fresh_lane_id()
+{
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    return ln;
+}
+
 __device__ __forceinline__ const float* uniform_ptr(const float* p)
 {
     const uintptr_t v = reinterpret_cast<uintptr_t>(p);

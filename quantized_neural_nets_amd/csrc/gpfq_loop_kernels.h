@@ -263,16 +263,21 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         // nothing but a fence orders one lane's store before another lane's load (the LDS itself executes a wave's
         // operations in order)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (c == 0 && lane < n) {
+        // The lane number is recomputed here, opaque to the compiler: everything derived from it below -- the per-lane
+        // 64-bit store addresses of every row, for both index widths -- is then defined INSIDE this rare block.  Left
+        // visible, the loop-invariant part of those addresses was hoisted out of the column loop and kept live across
+        // it: 24 VGPRs, which the 64-register variants (coop_lds_body) had to spill to scratch.
+        const int ln = fresh_lane_id();
+        if (c == 0 && ln < n) {
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
                 if (row0 + r < p.Ng) {
                     const int64_t gw = grow0 + r;
-                    p.Q[gw * p.ldq + t0 + lane] = hist[r * 64 + lane];
+                    p.Q[gw * p.ldq + t0 + ln] = hist[r * 64 + ln];
                     if (p.idx) {
-                        const int iv = __float_as_int(hist[(RT + r) * 64 + lane]);
-                        if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int8_t)iv;
-                        else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + lane] = (int16_t)iv;
+                        const int iv = __float_as_int(hist[(RT + r) * 64 + ln]);
+                        if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + ln] = (int8_t)iv;
+                        else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + ln] = (int16_t)iv;
                     }
                 }
             }
@@ -312,7 +317,10 @@ __device__ __forceinline__ void finish_row_w(const SlabParams& p, float qlast, b
         else win_final_sub16_s2<U, XL>(qlast);
     }
     if (!valid) return;
-    const int64_t kbase = (int64_t)seg * kSeg + 4 * lane;      // computed here: nothing 64-bit stays live across the loop
+    // computed here, from a lane number the compiler cannot see through: nothing 64-bit and per-lane is hoisted above
+    // the column loop and kept live across it (see the Q / idx flush in reducer_section)
+    lane = fresh_lane_id();
+    const int64_t kbase = (int64_t)seg * kSeg + 4 * lane;
     float* Urow = p.U + grow * p.ldu;
     float acc = 0.0f;
     auto chunk = [&](auto c_) {
@@ -635,7 +643,10 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
     constexpr int RT = 4, U0 = 64;                  // window = the four residual rows only (two interleaved pairs)
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [sweep waves][3][1024], seg[2][RT][NW], qs[2][RT+1], history
     const int NW = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave number as a SCALAR: everything derived from it (segment, LDS buffers, "am I a sweep wave") then lives in
+    // SGPRs -- the compiler has 64 VGPRs here, and as vector values the segment number and its 64-bit multiples were
+    // kept live across the column loop for the epilogue, in scratch
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int S = p.S, C = p.C;
     const int P = pow2_ceil(S);
     if (*static_cast<volatile const int*>(p.status) != 0) return;       // (a layer in rounds stops at the first timed-out launch)
@@ -680,15 +691,19 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* glb_ptr_t;
     // one column segment (1024 floats) of this wave into one LDS buffer: lane l brings elements 256 q + 4 l .. + 3 of quarter q
-    auto dma = [&](float* buf, const float* g) {
+    // (the global address is a wave-uniform base plus a 32-bit lane offset: one VGPR, where two per-lane 64-bit pointers
+    // advanced every step were four)
+    const unsigned lane_off = 16u * (unsigned)lane;
+    auto dma = [&](float* buf, const float* gbase) {
         lds_ptr_t l = (lds_ptr_t)(uintptr_t)buf;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, l, 16, 3072, 0);
+        glb_ptr_t g = (glb_ptr_t)(reinterpret_cast<const char*>(gbase) + lane_off);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(g, l, 16, 3072, 0);
     };
-    const float* xg = p.XT + (int64_t)myseg * kSeg + 4 * lane;
-    const float* ag = p.AT + (int64_t)myseg * kSeg + 4 * lane;
+    const float* xg = p.XT + (int64_t)myseg * kSeg;          // wave-uniform (the wave number is a scalar)
+    const float* ag = p.AT + (int64_t)myseg * kSeg;
     if (active) {
         // x_0 -> ring[0], a_0 -> a; ring[1] = x_{-1} = 0 (q_{-1} = 0)
         const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -820,9 +835,11 @@ GPFQ_DEFINE_COOP_MODES(1, 12, 2, 72, "v167")       // 168 - 80 - 16
 GPFQ_DEFINE_COOP_MODES(2, 8, 2, 144, "v255")       // 256 - 80 - 32
 GPFQ_DEFINE_COOP_MODES(2, 12, 2, 56, "v167")       // 168 - 80 - 32
 GPFQ_DEFINE_COOP_MODES(4, 8, 2, 112, "v255")       // 256 - 80 - 64
-// 168 - 48 - 64: three column buffers, one step of look-ahead.  No stochastic variant: the Philox rounds do not fit
-// the 56 registers left (two would spill); the host streams that combination instead (launch_coop -> UNSUPPORTED).
+// 168 - 48 - 64: three column buffers, one step of look-ahead, 56 registers for the compiler (the stochastic variant fits
+// them since the Q / idx flush and the epilogue recompute their lane number -- fresh_lane_id -- instead of keeping
+// per-lane store addresses live across the loop).
 GPFQ_DEFINE_COOP(4, 0, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 1, 12, 1, 56, "v167") GPFQ_DEFINE_COOP(4, 2, 12, 1, 56, "v167")
+GPFQ_DEFINE_COOP(4, 3, 12, 1, 56, "v167")
 // 128 - 48 - 32: two rows at 13..16 waves, for rows whose members would otherwise need a 13th sweep wave (P / C = 16 slots
 // per member and S / C just above 12: m = 803 840 is 785 segments, 12.3 per member at C = 64), one step of look-ahead.
 GPFQ_DEFINE_COOP_MODES(2, 16, 1, 48, "v127")
@@ -846,9 +863,7 @@ GPFQ_DEFINE_COOP_QUAD(0) GPFQ_DEFINE_COOP_QUAD(1) GPFQ_DEFINE_COOP_QUAD(2) GPFQ_
         asm volatile("" ::: "v127");                                                                              \
         coop_body<2, MODE, 1, 48, true>(p);                                                                       \
     }
-// (no stochastic variant: with the Philox rounds four registers would spill; the host streams that combination, as for the
-// four-row 12-wave kernel)
-GPFQ_DEFINE_COOP_OCT(0) GPFQ_DEFINE_COOP_OCT(1) GPFQ_DEFINE_COOP_OCT(2)
+GPFQ_DEFINE_COOP_OCT(0) GPFQ_DEFINE_COOP_OCT(1) GPFQ_DEFINE_COOP_OCT(2) GPFQ_DEFINE_COOP_OCT(3)
 // one row per group (depthwise convolutions with long rows), 12 waves: the one-row variant with per-row columns
 #define GPFQ_DEFINE_COOP_GROUPED(MODE)                                                                            \
     __global__ void __launch_bounds__(64 * 12) __attribute__((amdgpu_num_vgpr(72 / 2)))                            \

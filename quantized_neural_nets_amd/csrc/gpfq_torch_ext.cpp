@@ -66,7 +66,10 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> quantize_layer(const 
         return {Q, idx, U, usq};
     }
     const size_t wsb = gpfq_workspace_bytes(N, dg, m, (int)groups);
-    at::Tensor ws = at::zeros({(int64_t)wsb}, opts.dtype(at::kByte));      // zeroed: its head is the status / exchange scratch
+    // only the head of the workspace (exchange granules + status words) must start zeroed: the column buffers and the
+    // norms behind it are overwritten in full by the column preparation (hundreds of MB for a ResNet-50 3x3 layer)
+    at::Tensor ws = at::empty({(int64_t)wsb}, opts.dtype(at::kByte));
+    ws.narrow(0, 0, (int64_t)gpfq_scratch_bytes()).zero_();
     void* stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(W.device().index()).stream();
     auto run = [&](int p) {
         const int rc = gpfq_quantize_layer_f32(W.data_ptr<float>(), A.data_ptr<float>(), lda, X.data_ptr<float>(), ldx, N, dg, m,

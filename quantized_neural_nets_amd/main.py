@@ -71,13 +71,21 @@ class AlexNetArch(nn.Sequential):
             nn.Dropout(), nn.Linear(4096, 4096), nn.ReLU(inplace=True), nn.Linear(4096, num_classes))
 
 
-def load_model(name):
+def load_model(name, data_set='ILSVRC2012'):
+    """Returns (model, pretrained): ILSVRC2012 -> torchvision's pretrained model (main.py:61-62); CIFAR10 -> the
+    checkpoint pretrained_cifar10/<model>_cifar10.pt (main.py:76-79).  pretrained is False for the random-init AlexNet
+    stand-in used when torchvision is not installed."""
+    if data_set == 'CIFAR10':
+        path = os.path.join('pretrained_cifar10', name + '_cifar10.pt')
+        if not os.path.isfile(path):
+            raise SystemExit("-ds CIFAR10 needs the checkpoint %s (main.py:76-79 of the reference loads it)" % path)
+        return torch.load(path, map_location=torch.device('cpu'), weights_only=False).module, True
     try:
         import torchvision
-        return getattr(torchvision.models, name)(pretrained=True)
+        return getattr(torchvision.models, name)(pretrained=True), True
     except ImportError:
         if name == 'alexnet':
-            return AlexNetArch()
+            return AlexNetArch(), False
         raise SystemExit("torchvision is not installed: only `-model alexnet` (random init) is available")
 
 
@@ -97,7 +105,8 @@ class SyntheticLoader:
 LOG_FIELDS = ['Model Name', 'Dataset', 'Quantization Batch Size', 'Original Top1 Accuracy', 'Quantized Top1 Accuracy',
               'Original Top5 Accuracy', 'Quantized Top5 Accuracy', 'Bits', 'MLP_Alphabet_Scalar', 'CNN_Alphabet_Scalar',
               'MLP_Percentile', 'CNN_Percentile', 'Stochastic Quantization', 'Regularizer', 'Lambda', 'Original Sparsity',
-              'Quantized Sparsity', 'Retain_rate', 'Fusion', 'Seed']
+              'Quantized Sparsity', 'Retain_rate', 'Fusion', 'Seed',
+              'Cooperative Timeouts']      # extra trailing column: layers redone after a cooperative kernel gave up waiting
 
 # FP32 top-1 / top-5 of the un-quantized torchvision models, as the reference tabulates them (main.py:65-74)
 ORIGINAL_ACCURACY = {
@@ -134,7 +143,8 @@ def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
     device = torch.device("cuda:0")
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
-    model = load_model(args.model).to(device).eval()
+    model, pretrained = load_model(args.model, args.data_set)
+    model = model.to(device).eval()
     if args.fusion:
         fusion_layers_inplace(model, device)
         print('CNN and BN layers are fused before quantization!\n')
@@ -177,7 +187,10 @@ def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
               % (args.save_packed, info["layers"], info["packed_bytes"] / 1e6, info["fp32_bytes"] / 1e6))
     orig_acc, acc = ('', ''), ('', '')
     if test_loader is not None:
-        orig_acc = ORIGINAL_ACCURACY.get(args.model) or test_accuracy(model, test_loader, device, (1, 5))
+        # the tabulated FP32 accuracies are those of torchvision's ImageNet weights (main.py:65-74: the table exists for
+        # ILSVRC2012 only); any other model is evaluated (main.py:143-146)
+        tabulated = ORIGINAL_ACCURACY.get(args.model) if (args.data_set == 'ILSVRC2012' and pretrained) else None
+        orig_acc = tabulated or test_accuracy(model, test_loader, device, (1, 5))
         print(f'Top-1 accuracy of {args.model} is {orig_acc[0]}.')
         print(f'Top-5 accuracy of {args.model} is {orig_acc[1]}.')
         acc = test_accuracy(quantized_model, test_loader, device, (1, 5))
@@ -188,7 +201,8 @@ def run(args, bits, mlp_s, cnn_s, bs, mlp_per, cnn_per, lamb):
     if args.log_file:
         append_log_row(args.log_file, [args.model, args.data_set, bs, orig_acc[0], acc[0], orig_acc[1], acc[1], bits, mlp_s, cnn_s,
                                        mlp_per, cnn_per, args.stochastic_quantization, args.regularizer, lamb,
-                                       original_sparsity, quantized_sparsity, args.retain_rate, args.fusion, args.seed])
+                                       original_sparsity, quantized_sparsity, args.retain_rate, args.fusion, args.seed,
+                                       sum(len(r.get('timeouts', ())) for r in quantizer.layer_reports)])
     return quantizer
 
 

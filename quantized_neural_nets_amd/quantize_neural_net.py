@@ -119,8 +119,14 @@ class QuantizeNeuralNet:
 
             print(f'The quantization error of layer {layer_idx} is {quantize_error.cpu().numpy()}.')
             print(f'The relative quantization error of layer {layer_idx} is {relative_quantize_error.cpu().numpy()}.\n')
+            if res["timeouts"]:
+                # a cooperative launch gave up waiting for a peer workgroup (the card is shared, or co-residency broke)
+                # and the layer was redone on the plan that waits for nobody: correct, but slow -- say so
+                print(f'WARNING: layer {layer_idx}: {len(res["timeouts"])} cooperative launch(es) timed out and were '
+                      f'redone on the whole-row streaming plan (rows, d, m): {res["timeouts"]}')
             self.layer_reports.append(dict(layer=layer_idx, quantize_error=float(quantize_error),
-                                           relative_quantize_error=float(relative_quantize_error)))
+                                           relative_quantize_error=float(relative_quantize_error),
+                                           timeouts=list(res["timeouts"])))
             mode = 1 if self.reg == 'L1' else 2 if self.reg == 'L0' else 3 if self.stochastic_quantization else 0
             self.layer_indices.append(dict(layer=layer_idx, idx=res["idx"].detach().cpu(), step=float(res["step"]),
                                            K=int(K), mode=mode, lamb=float(self.lamb if self.lamb is not None else 0.0)))

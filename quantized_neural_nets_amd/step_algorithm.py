@@ -176,12 +176,13 @@ class StepAlgorithm:
 
         if plan != _lib.PLAN_STREAM_ROWS and N > 0 and d > 0:
             # this surface updates U in place, so a launch that gives up waiting for a peer workgroup has already
-            # spoilt its input: keep a copy whenever the plan about to run is one that can time out
-            desc = _lib.describe_plan(N, d, m, 1, _lib.PLAN_STREAM if plan == _lib.PLAN_AUTO else plan)
-            if desc.startswith("coop") or " C=" in desc:
-                U0 = Uv.clone()
+            # spoilt its input: keep a copy whenever the launch MAY wait on other workgroups -- any plan but whole-row
+            # streaming (the plan that runs is decided inside the library: fallbacks, GPFQ_* overrides)
+            U0 = Uv.clone()
         if launch(plan) and not _lib.status_ok(dev):
             # never hand back what a timed-out launch left behind: redo on the plan that waits for nobody
+            if U0 is None:
+                raise _lib.GpfqError("a cooperative launch timed out and no copy of the initial residual was kept")
             Uv.copy_(U0)
             launch(_lib.PLAN_STREAM_ROWS)
         if Qv.data_ptr() != Q.data_ptr():

@@ -105,12 +105,18 @@ def test_the_built_isa_passes():
             kernels[cur].append(ln)
             if ln.strip().startswith("s_endpgm"):
                 cur = None
-    checked, bad = 0, []
+    checked, bad, unguarded = 0, [], []
     for name, lines in kernels.items():
-        has, problems = cal.check_kernel(name, lines)
-        checked += has
+        kind, problems = cal.check_kernel(name, lines)
+        checked += kind is not None
         bad += problems
-    assert checked >= 20 and bad == []
+        # every register-resident kernel (resident_* / coop_*, the LDS-staged four-row family included) keeps its
+        # residual rows in a reserved window: each of them must be under the window guard, none may be skipped
+        if ("gpfq_resident_" in name or "gpfq_coop_" in name) and kind != "window":
+            unguarded.append(name)
+    assert checked >= 100 and bad == [] and unguarded == []
+    assert sum(1 for n in kernels if "w16l" in n) == 8          # the LDS-staged family is in the ISA that was checked
+    assert not any(ln.strip().startswith("scratch_") for lines in kernels.values() for ln in lines)   # no kernel spills
 
 
 # ---- column-window kernels (registers written as base+offset sums, reserved from the compiler) ----------------------
@@ -141,3 +147,33 @@ def test_compiler_code_in_the_window_is_caught():
 def test_spill_in_a_window_kernel_is_caught():
     bad = run(win_load(176, 0) + asm_wait(0) + ["\tscratch_store_dword off, v3, off offset:4"])
     assert len(bad) == 1 and "spills" in bad[0]
+
+
+# ---- window kernels that stage their columns through LDS (no asm loads into registers: the window is the residual rows)
+def lds_sweep(base):
+    return ["\t;;#ASMSTART", "\tv_pk_mul_f32 v[10:11], v[20:21], v[30:31] op_sel:[0,0] op_sel_hi:[1,0]",
+            "\tv_pk_add_f32 v[%d+0:%d+1], v[%d+0:%d+1], v[10:11] neg_lo:[0,1] neg_hi:[0,1]" % (base, base, base, base), "\t;;#ASMEND"]
+
+
+LDS_DMA = ["\tglobal_load_lds_dwordx4 v5, s[10:11] offset:1024"]
+
+
+def test_lds_staged_kernel_is_a_window_kernel():
+    kind, problems = cal.check_kernel("k", LDS_DMA + lds_sweep(64) + ["\tv_add_f32_e32 v20, v21, v22", "\ts_endpgm"])
+    assert kind == "window" and problems == []
+    assert cal.window_start(lds_sweep(64)) == 64
+
+
+def test_lds_staged_kernel_compiler_code_in_the_window_is_caught():
+    kind, problems = cal.check_kernel("k", LDS_DMA + lds_sweep(64) + ["\tv_mov_b32_e32 v70, v3", "\ts_endpgm"])
+    assert kind == "window" and len(problems) == 1 and "window starts at v64" in problems[0]
+
+
+def test_lds_staged_kernel_spill_is_caught():
+    kind, problems = cal.check_kernel("k", LDS_DMA + lds_sweep(64) + ["\tscratch_store_dwordx2 off, v[12:13], off offset:20", "\ts_endpgm"])
+    assert kind == "window" and len(problems) == 1 and "spills" in problems[0]
+
+
+def test_lds_dma_without_a_window_is_flagged_not_skipped():
+    kind, problems = cal.check_kernel("k", LDS_DMA + ["\tscratch_load_dword v0, off, off", "\ts_endpgm"])
+    assert kind == "lds-dma" and len(problems) == 1

@@ -87,8 +87,13 @@ def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, mode):
     draws: equality with the oracle (keyed by global rows) and with the streaming plan shows it."""
     from quantized_neural_nets_amd import _lib
     omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
-    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (3, 3, 3212288)):   # (the last: two rows x 256 members; stochastic streams)
-        assert "rounds=" in _lib.describe_plan(N, d, m)
+    lmode = {"soft": _lib.MODE_SOFT, "hard": _lib.MODE_HARD, "stochastic": _lib.MODE_STOCHASTIC}[mode]
+    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (3, 3, 3212288)):   # (the last: two rows x 256 members -- a variant
+        # without a stochastic form: the plan chosen, and described, for that quantizer is the next-best cooperative pair)
+        desc = _lib.describe_plan(N, d, m, 1, 0, lmode)
+        assert "rounds=" in desc, desc
+        if mode == "stochastic":
+            assert not desc.startswith("coop RT=2 C=256") and desc.startswith("coop"), desc
         W, A, X = bw.synthetic_layer(N, d, m, 91 + N, first_layer=False)
         step = bw.layer_step(W)
         r = _run(W, A, X, m, 0, mode=mode, seed=4321, step=step)

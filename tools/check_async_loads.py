@@ -7,6 +7,10 @@ while the load may still be in flight -- in particular nothing the compiler adds
 temporary parked in the register).  This script replays the ISA of those kernels
 (`make -C quantized_neural_nets_amd/csrc asm` writes it to csrc/build/) in program order:
 
+  * a kernel whose asm statements name registers in the window notation (base+offset sums) is a WINDOW kernel: its
+    window -- from the lowest such register up -- may be named by no compiler-generated instruction, and it may not
+    spill; this covers the kernels whose column buffers are asm-loaded registers AND those that stage their columns
+    through LDS (`global_load_lds`) and keep only the residual rows in the window.  For the others:
   * an inline-asm `global_load_dwordx4 vD, ...` puts the registers of vD in flight, in issue order;
   * an inline-asm `s_waitcnt vmcnt(N)` lands every load except the N youngest asm loads (the counter retires in
     order; loads and stores the compiler issues itself only make the hardware wait longer);
@@ -53,10 +57,11 @@ def vregs(line):
     return out
 
 
-def window_violations(name, lines):
-    """Kernels that keep their column buffers in a reserved register window (gpfq_device.h win_*): the window is
-    everything from the lowest destination of an asm load upwards, and NO instruction outside an asm statement may
-    name a register in it -- the compiler must not know those registers exist."""
+def window_start(lines):
+    """First register of a kernel's reserved window: the lowest register any asm statement names in the window
+    statements' own notation, base+offset sums (v[64+2:64+3]) -- column buffers the asm loads write, and residual rows
+    the asm sweeps update in place (the only window registers of the kernels that stage their columns through LDS).
+    None: the kernel has no window."""
     lo = None
     in_asm = False
     for ln in lines:
@@ -65,9 +70,19 @@ def window_violations(name, lines):
             in_asm = True
         elif st.startswith(";;#ASMEND"):
             in_asm = False
-        elif in_asm and st.startswith("global_load_dwordx4") and "+" in st.split()[1]:
-            r = regs_of(st.split()[1].rstrip(","))
-            lo = min(r) if lo is None else min(lo, min(r))
+        elif in_asm:
+            for tok in re.findall(r"v\[[\d+]+(?::[\d+]+)?\]", st.split(";")[0]):
+                if "+" in tok:
+                    r = regs_of(tok)
+                    lo = min(r) if lo is None else min(lo, min(r))
+    return lo
+
+
+def window_violations(name, lines):
+    """Kernels that keep column buffers and / or residual rows in a reserved register window (gpfq_device.h win_*): the
+    window is everything from window_start() upwards, and NO instruction outside an asm statement may name a register
+    in it -- the compiler must not know those registers exist."""
+    lo = window_start(lines)
     if lo is None:
         return []
     out = []
@@ -132,34 +147,45 @@ def replay(name, lines, inflight, problems, report):
 
 
 def is_window_kernel(lines):
-    return any(l.strip().startswith("global_load_dwordx4") and "+" in l.strip().split()[1] and
-               lines[i - 1].strip().startswith(";;#ASMSTART") for i, l in enumerate(lines) if i > 0)
+    return window_start(lines) is not None
+
+
+def uses_lds_dma(lines):
+    return any(l.strip().startswith("global_load_lds") for l in lines)
+
+
+def spills(name, lines):
+    return ["%s: line %d spills in a kernel with a register window / hand-waited loads: %s" % (name, no, ln.strip())
+            for no, ln in enumerate(lines) if ln.strip().startswith("scratch_")]
 
 
 def check_kernel(name, lines):
-    if not any(l.strip().startswith("global_load_dwordx4") and lines[i - 1].strip().startswith(";;#ASMSTART")
-               for i, l in enumerate(lines) if i > 0):
-        return False, []
+    """-> (kind, problems); kind: "window" (reserved register window: column buffers and / or residual rows),
+    "replay" (hand-waited asm loads into compiler-allocated registers), "lds-dma" (global_load_lds without a window:
+    only the spill check applies), or None (nothing hand-managed: not checked)."""
+    asm_loads = any(l.strip().startswith("global_load_dwordx4") and lines[i - 1].strip().startswith(";;#ASMSTART")
+                    for i, l in enumerate(lines) if i > 0)
     if is_window_kernel(lines):
-        # Column-window kernels (gpfq_device.h win_*): the registers with loads in flight are never compiler values, so
-        # what has to hold on the ISA is (1) no instruction outside an asm statement names a window register and (2)
-        # nothing is spilt.  That every sweep is behind a wait covering its columns is a property of the SOURCE: all
-        # window statements are `asm volatile`, which the compiler keeps in program order on every path, and the
-        # vmcnt arithmetic is the parity tests' job (a linear replay of the text cannot follow these kernels' spin loops).
-        problems = window_violations(name, lines)
-        problems += ["%s: line %d spills in a column-window kernel: %s" % (name, no, ln.strip())
-                     for no, ln in enumerate(lines) if ln.strip().startswith("scratch_")]
-        return True, problems
-    problems = []
-    inflight = []
-    replay(name, lines, inflight, problems, True)
-    # second pass from the loop-bottom state: only the loop body matters, duplicates are dropped below
-    seen = set(problems)
-    again = []
-    replay(name, lines, inflight, again, True)
-    problems += [p for p in again if p not in seen and "loads into register(s) still in flight" not in p]
-    problems += window_violations(name, lines)
-    return True, problems
+        # Window kernels (gpfq_device.h win_*): the registers with loads in flight, and the residual rows updated in place,
+        # are never compiler values, so what has to hold on the ISA is (1) no instruction outside an asm statement names a
+        # window register and (2) nothing is spilt.  That every sweep is behind a wait covering its columns is a property
+        # of the SOURCE: all window statements are `asm volatile`, which the compiler keeps in program order on every
+        # path, and the vmcnt arithmetic is the parity tests' job (a linear replay of the text cannot follow these
+        # kernels' spin loops).
+        return "window", window_violations(name, lines) + spills(name, lines)
+    if asm_loads:
+        problems = []
+        inflight = []
+        replay(name, lines, inflight, problems, True)
+        # second pass from the loop-bottom state: only the loop body matters, duplicates are dropped below
+        seen = set(problems)
+        again = []
+        replay(name, lines, inflight, again, True)
+        problems += [p for p in again if p not in seen and "loads into register(s) still in flight" not in p]
+        return "replay", problems
+    if uses_lds_dma(lines):
+        return "lds-dma", spills(name, lines)
+    return None, []
 
 
 def main():
@@ -177,16 +203,27 @@ def main():
             if ln.strip().startswith("s_endpgm"):
                 cur = None
     bad = []
-    checked = 0
+    kinds = {}
+    skipped = []
+    nspill = 0
     for name, lines in kernels.items():
-        has, problems = check_kernel(name, lines)
-        if has:
-            checked += 1
+        kind, problems = check_kernel(name, lines)
+        nspill += sum(1 for ln in lines if ln.strip().startswith("scratch_"))
+        if kind is None:
+            skipped.append(name)
+        else:
+            kinds[kind] = kinds.get(kind, 0) + 1
             bad += problems
     for b in bad:
         print(b)
-    print("%d kernels with hand-waited loads checked, %d problem(s)" % (checked, len(bad)))
-    return 1 if bad or checked == 0 else 0
+    checked = sum(kinds.values())
+    lds_unwindowed = kinds.get("lds-dma", 0)
+    print("%d kernels, %d checked (%s), %d not checked (no asm loads, no register window, no LDS DMA: %s), "
+          "%d skipped window kernels, %d scratch instruction(s) in all kernels, %d problem(s)" % (
+              len(kernels), checked, ", ".join("%d %s" % (v, k) for k, v in sorted(kinds.items())), len(skipped),
+              ", ".join(sorted(set(re.sub(r"_ZN4gpfq\d+|ILi.*|EN?S_.*|E?v?P.*", "", n) for n in skipped))) or "-",
+              lds_unwindowed, nspill, len(bad)))
+    return 1 if bad or checked == 0 or lds_unwindowed else 0
 
 
 if __name__ == "__main__":
