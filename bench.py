@@ -60,6 +60,19 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--layer-table", default=None, help="also write the per-layer table to this file")
+    ap.add_argument("--max-cols", type=int, default=None,
+                    help="test runs: keep only the first MAX_COLS input features per group of every layer (full N, m, groups: the "
+                         "plan and the kernels are those of the full layer; fewer steps and a fraction of the input generation)")
+    ap.add_argument("--distinct-shapes", action="store_true",
+                    help="test runs: one layer per distinct (N, d_g, m, groups) shape of the workload")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="with --gpus 1: initialise a ONE-rank process group on --backend (nccl = RCCL) and take the sharded "
+                         "path (dist.enable(force=True)): every layer goes through all_gather_into_tensor / all_reduce on the GPU")
+    ap.add_argument("--prefetch-analog", action="store_true",
+                    help="prepare the ANALOG columns of layer i+1 on a side stream while the loop of layer i runs (they do not "
+                         "depend on the layers quantized before; the quantized columns stay serial, as in the real driver)")
+    ap.add_argument("--oracle-budget", type=float, default=2e9,
+                    help="oracle_shape_check: rows x columns x m per shape the CPU oracle is given (0 = skip the check)")
     return ap.parse_args()
 
 
@@ -146,6 +159,52 @@ def cpu_baseline(data, gpu_idx, budget_s=20.0):
                   "mismatches": mismatches}
 
 
+def oracle_shape_check(data, layers, gpu_idx, K, mode, lamb, budget):
+    """Every DISTINCT (N, d_g, m, groups) shape of the workload against the CPU oracle (oracle/gpfq_oracle.c), on the
+    inputs the timed run just quantized: rows of a layer are independent and column t depends on columns < t only, so
+    the oracle is run on a sample of rows (the first and the last of the layer / of the first and last groups: tile
+    tails included) over the first columns, and must reproduce the timed run's indices there bit for bit.
+    Sample per shape: rows x columns x m <= budget (at most 32 rows, at most 64 columns, at least 4)."""
+    import numpy as np
+    import torch
+    import oracle
+    nthreads = min(os.cpu_count() or 1, 32)
+    seen, nshape, checked, bad, worst = set(), 0, 0, 0, []
+    t0 = time.perf_counter()
+    geom = {l[0]: l[1:5] for l in layers}
+    for name, W, A, X, step, m in data:
+        N, dg, m_, groups = geom[name]
+        key = (N, dg, m, groups)
+        if key in seen:
+            continue
+        seen.add(key)
+        Ng = N // groups
+        gsel = sorted(set(list(range(min(groups, 2))) + list(range(max(groups - 2, 0), groups))))
+        per_g = max(1, 32 // len(gsel))
+        rsel = sorted(set(list(range(min(Ng, (per_g + 1) // 2))) + list(range(max(Ng - per_g // 2, 0), Ng))))
+        nrows = len(gsel) * len(rsel)
+        cols = int(max(4, min(dg, 64, budget // max(1, nrows * m))))
+        cols = min(cols, dg)
+        for g in gsel:
+            rows = torch.tensor([g * Ng + r for r in rsel], device=W.device)
+            Wg = W.index_select(0, rows)[:, :cols].cpu().numpy()
+            Ag = A[:, g * dg:g * dg + cols].cpu().numpy()
+            Xg = X[:, g * dg:g * dg + cols].cpu().numpy()
+            # (row_id0 only keys the stochastic quantizer, which no workload uses)
+            _, idxc, _ = oracle.quantization(Wg, Ag, Xg, step, K, mode=mode, lamb=lamb, nthreads=nthreads)
+            got = gpu_idx[name].index_select(0, rows)[:, :cols].cpu().numpy().astype(np.int16)
+            nb = int((got != idxc).sum())
+            bad += nb
+            checked += got.size
+            if nb:
+                worst.append("%s group %d: %d of %d" % (name, g, nb, got.size))
+        nshape += 1
+    log("oracle shape check: %d distinct shapes, %d weights, %d mismatches, %.1fs" % (nshape, checked, bad, time.perf_counter() - t0))
+    return {"against": "CPU oracle (oracle/gpfq_oracle.c) on the timed run's inputs: first/last rows x first columns of every "
+                       "distinct (N, d_g, m, groups) shape", "shapes": nshape, "weights": checked, "mismatches": bad,
+            "failed": worst[:8]}
+
+
 def kernel_name(desc, mode=0):
     """The template instantiation a plan description launches (quantized_neural_nets_amd/csrc launch_slab):
     the names rocprofv3 reports."""
@@ -210,8 +269,73 @@ def pmc_traffic(kernel, digest):
     return None, ("no PMC summary for this kernel source (newest other: %s): collect with tools/pmc_traffic.py" % stale)
 
 
+def pmc_counters(kernel, digest):
+    """Per-launch hardware counters of `kernel` from a committed rocprofv3 PMC summary (tools/profile_counters.sh ->
+    tools/pmc_counters.py: one pass per counter group of this same command) -- ONLY from a summary stamped with the digest
+    of the kernel sources this run was built from; otherwise (None, reason)."""
+    import glob
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters.json")), reverse=True):
+        data = json.load(open(path))
+        if data.get("source_sha256") != digest:
+            stale = stale or os.path.relpath(path, ROOT)
+            continue
+        for name, v in data.get("kernels", {}).items():
+            if kernel in name:
+                return v, os.path.relpath(path, ROOT)
+    return None, ("no counter summary for this kernel source (newest other: %s): collect with tools/profile_counters.sh" % stale)
+
+
+def counter_rooflines(dom, fam_rec, digest, l2_model):
+    """The two bounded, counter-backed rooflines of the dominant register-resident kernel.
+    roofline_issue: the kernel runs one wave per SIMD and a wave issues in order, so what bounds a step is its own
+      instruction stream: SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = the fraction of the waves' lifetime in which they have an
+      instruction executing (both in quad-cycles, summed over the launch's waves: <= 1 by construction; the rest is
+      SQ_WAIT_ANY -- s_waitcnt / barrier -- and SQ_WAIT_INST_ANY -- issue stalls).
+    roofline_l2 (measured): TCP_TCC_READ_REQ_sum x 128 B per launch / the launch time measured live in this run /
+      34.5 TB/s -- the column traffic the CUs really pull from L2, next to the model (8 * m_pad per row tile per step)."""
+    rec, src = pmc_counters(dom, digest)
+    if rec is None:
+        return None, src
+    c = rec["per_launch"]
+    need = ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAVES")
+    if any(k not in c for k in need):
+        return None, "%s lacks %s" % (src, [k for k in need if k not in c])
+    wc = c["SQ_WAVE_CYCLES"]
+    issue = {"bound": "issue", "kernel": dom, "achieved": c["SQ_ACTIVE_INST_ANY"], "peak": wc,
+             "unit": "wave quad-cycles per launch", "frac": round(c["SQ_ACTIVE_INST_ANY"] / wc, 4),
+             "valu_frac": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4),
+             "wait_frac": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+             "issue_stall_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4),
+             "insts_per_wave": {k[len("SQ_INSTS_"):].lower(): round(c[k] / c["SQ_WAVES"], 1) for k in sorted(c)
+                                if k.startswith("SQ_INSTS_")},
+             "waves_per_launch": c["SQ_WAVES"], "launches_profiled": rec["launches"], "source": src,
+             "definition": "SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES of the kernel's launches (rocprofv3 --pmc, averaged per "
+                           "launch): the fraction of its waves' lifetime with an instruction executing; one wave per SIMD, "
+                           "in-order issue -- the instruction stream of the step is what bounds it"}
+    l2 = None
+    if "TCP_TCC_READ_REQ_sum" in c and fam_rec["launches"]:
+        by = c["TCP_TCC_READ_REQ_sum"] * 128.0
+        t = fam_rec["ms"] / fam_rec["launches"] * 1e-3
+        hit = c.get("TCC_HIT_sum")
+        miss = c.get("TCC_MISS_sum")
+        l2 = {"bound": "l2", "kernel": dom, "achieved": round(by / t / 1e9, 1), "peak": L2_PEAK_GBPS, "unit": "GB/s",
+              "frac": round(by / t / 1e9 / L2_PEAK_GBPS, 4), "measured": True,
+              "read_requests_per_launch": c["TCP_TCC_READ_REQ_sum"], "request_bytes": 128,
+              "l2_hit_rate": round(hit / (hit + miss), 4) if hit is not None and miss else None,
+              "fabric_read_requests_per_launch": c.get("TCC_EA0_RDREQ_sum"),
+              "avg_launch_ms": round(t * 1e3, 4), "source": src,
+              "definition": "TCP_TCC_READ_REQ_sum (vector-L1 -> L2 read requests, 128 B each: calibrated on the column "
+                            "preparation kernel, whose bytes are known) per launch x 128 B / the launch time measured by "
+                            "events in THIS run / the 34.5 TB/s L2 aggregate of MI355X_MICROARCH.md",
+              "model": l2_model}
+    return {"issue": issue, "l2": l2}, src
+
+
 def main():
     args = parse_args()
+    if args.capture and (args.max_cols or args.distinct_shapes):
+        sys.exit("bench.py: --capture takes the full layers (no --max-cols / --distinct-shapes)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))          # before any GPU call: this process never initialises HIP
 
@@ -231,12 +355,22 @@ def main():
     from quantized_neural_nets_amd import StepAlgorithm, _lib, dist as qdist
     from quantized_neural_nets_amd.step_algorithm import PreparedColumns
     import torch.distributed as td
-    if world > 1:
+    if args.force_shard and world == 1:
+        # a process group of ONE rank: the sharded path's collectives run for real (nccl = RCCL), as identities
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.force_shard:
         if args.backend == "nccl":
             td.init_process_group("nccl", device_id=dev)
         else:
             td.init_process_group(args.backend)
-        qdist.enable()
+        qdist.enable(force=args.force_shard)
     # host threads for the input generation: torchrun pins OMP_NUM_THREADS to 1 per rank; share the cores instead
     torch.set_num_threads(max(1, min(32, (os.cpu_count() or 1) // max(world, 1))))
 
@@ -252,6 +386,15 @@ def main():
     layers = bw.normalize_layers(layer_fn(args.batch))          # (name, N, d_g, m, groups[, conv geometry])
     if args.layers:
         layers = [l for l in layers if args.layers in l[0]]
+    if args.distinct_shapes:
+        seen_shapes, keep = set(), []
+        for l in layers:
+            if l[1:5] not in seen_shapes:
+                seen_shapes.add(l[1:5])
+                keep.append(l)
+        layers = keep
+    if args.max_cols:
+        layers = [(l[0], l[1], min(l[2], args.max_cols)) + tuple(l[3:]) for l in layers]
     total_weights = sum(l[1] * l[2] for l in layers)
     alg_bytes = {l[0]: bw.algorithmic_bytes(l[1], l[2], l[3], l[4]) for l in layers}
 
@@ -313,17 +456,44 @@ def main():
                                                  compute_errors=False, step_override=step, plan=plan_, event_hook=hook_)
         return r
 
+    side = torch.cuda.Stream(device=dev) if args.prefetch_analog and not args.capture else None
+
     def one_step(keep=False):
-        for name, W, A, X, step, m in data:
+        ahead = {}                                   # layer position -> (PreparedColumns, event on the side stream)
+        main = torch.cuda.current_stream(dev)
+        for i, (name, W, A, X, step, m) in enumerate(data):
             cur["name"] = name
-            r = run_layer(name, W, A, X, step, m, plan, hook)
+            hook_i = hook
+            if side is not None:
+                if i in ahead:                       # the analog columns were prepared while the previous loop ran
+                    P, done = ahead.pop(i)
+                    main.wait_event(done)
+                    P.T.record_stream(main)
+                    A = P
+                if i + 1 < len(data):
+                    nxt = data[i + 1][2]
+
+                    def hook_i(tag, shape, nxt=nxt, i=i):
+                        hook(tag, shape)
+                        if tag == "loop_begin" and (i + 1) not in ahead:   # right before this layer's loop is launched: start the next layer's
+                            ev = torch.cuda.Event()  # analog transposition behind everything queued so far
+                            ev.record(main)
+                            with torch.cuda.stream(side):
+                                side.wait_event(ev)
+                                Pn = StepAlgorithm.prepare_columns(nxt)
+                                dn = torch.cuda.Event()
+                                dn.record(side)
+                            ahead[i + 1] = (Pn, dn)
+            r = run_layer(name, W, A, X, step, m, plan, hook_i)
             timeouts.extend(r["timeouts"])
             if keep:
                 last_idx[name] = r["idx"]
 
+    pg = world > 1 or args.force_shard          # a process group exists
+
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if pg:
             td.barrier()
         torch.cuda.synchronize()
 
@@ -339,7 +509,7 @@ def main():
     elapsed = time.perf_counter() - t0
     cur["on"] = False
     _lib.check_status(dev)
-    if world > 1:
+    if pg:
         tmax = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -421,7 +591,8 @@ def main():
             digest = _lib.kernel_source_digest()
             # the PMC passes behind the committed summary run the HEADLINE workload (tools/profile_bench.sh): the same kernel
             # name launched on another workload's shapes moves other bytes, so nothing is quoted there
-            if args.workload == "r50_3x3" and args.layers is None and default_batch and world == 1:
+            if args.workload == "r50_3x3" and args.layers is None and default_batch and world == 1 and not args.max_cols \
+                    and not args.distinct_shapes:
                 traffic, tsrc = pmc_traffic(dom, digest)
             else:
                 traffic, tsrc = None, "PMC summaries are collected on the headline workload only (tools/profile_bench.sh)"
@@ -450,6 +621,16 @@ def main():
                                              "peak = MI355X_MICROARCH.md L2 aggregate 34.5 TB/s",
                                "whole_job_frac": round(sum(v["l2"] for v in fam.values() if v["l2_known"]) /
                                                        (sum(v["ms"] for v in fam.values() if v["l2_known"]) * 1e-3) / 1e9 / L2_PEAK_GBPS, 4)}
+        roofline_issue = None
+        if dom and fam[dom]["l2_known"] and args.workload == "r50_3x3" and args.layers is None and default_batch and world == 1 \
+                and not args.max_cols and not args.distinct_shapes:
+            cr, csrc = counter_rooflines(dom, fam[dom], _lib.kernel_source_digest(), roofline_l2)
+            if cr:
+                roofline_issue = cr["issue"]
+                if cr["l2"]:
+                    roofline_l2 = cr["l2"]
+            else:
+                roofline_issue = {"bound": "issue", "kernel": dom, "frac": None, "source": csrc}
         cfg_desc = "%d-bit (K=%d)%s, scalar 1.16, retain_rate 0.25" % (bits, K, ", %s lamb %g" % (reg, lamb) if reg else "")
         out = {
             "metric": "M weights quantized/sec (GPFQ loop), %s, calib batch %d"
@@ -466,26 +647,33 @@ def main():
             "config": {"workload": workload_desc + ", calibration batch %d, %s" % (args.batch, cfg_desc),
                        "layers": len(layers), "weights": total_weights,
                        "algorithmic_bytes": sum(alg_bytes.values()),
-                       "column_prep": "fused patch gather from feature maps (driver path)" if args.capture else "transpose of (m, d) matrices",
-                       "parallelism": "neuron-shard x%d + all_gather(int8 idx)" % world if world > 1 else "single GPU"},
+                       "column_prep": "fused patch gather from feature maps (driver path)" if args.capture else
+                                      "transpose of (m, d) matrices" + ("; analog columns one layer ahead on a side stream" if side is not None else ""),
+                       "parallelism": ("neuron-shard x%d + all_gather(int8 idx)" % world if world > 1 else
+                                       "single GPU, sharded path forced (one-rank %s group)" % args.backend if args.force_shard else "single GPU")},
             "roofline_whole_job_frac": round(sum(alg_bytes.values()) * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS / max(world, 1), 4),
             "prep_ms_per_step": round(prep_ms_total, 3), "loop_ms_per_step": round(loop_ms_total, 3),
             "cooperative_timeouts": len(timeouts),
             "roofline": roofline,
             "roofline_l2": roofline_l2,
+            "roofline_issue": roofline_issue,
             "output_check": output_check,
         }
         failed = bool(output_check and output_check["mismatches"])
-        if world == 1 and not args.no_cpu_baseline and args.workload == "r50_3x3" and not args.capture and not args.layers:
+        if not args.no_output_check and not args.capture and args.oracle_budget > 0:
+            out["oracle_shape_check"] = oracle_shape_check(data, layers, last_idx, K, mode, lamb, args.oracle_budget)
+            failed = failed or bool(out["oracle_shape_check"]["mismatches"])
+        if world == 1 and not args.no_cpu_baseline and args.workload == "r50_3x3" and not args.capture and not args.layers \
+                and not args.max_cols and not args.distinct_shapes:
             out["cpu_baseline"], out["oracle_check"] = cpu_baseline(data, last_idx)
             failed = failed or bool(out["oracle_check"]["mismatches"])
         print(json.dumps(out), flush=True)
         if failed:
             log("bench.py: OUTPUT CHECK FAILED")
-            if world > 1:
+            if pg:
                 td.destroy_process_group()
             sys.exit(3)
-    if world > 1:
+    if pg:
         td.destroy_process_group()
 
 

@@ -99,9 +99,21 @@ int gpfq_last_launch_used_exchange(void);
  * step_algorithm.py:141-148 (analog_layer_input[:, t], quantized_layer_input[:, t]).
  *   A, X   [m][lda / ldx]   D = number of columns used (groups * d_g)
  *   AT, XT [D][m_pad]       nrm2 [2 * D]  (pairs; a group's slice starts at 2 * g * d_g)
+ * One of A, X may be NULL: that matrix is skipped (its outputs are not touched; nrm2 belongs to X) -- the analog columns
+ * do not depend on the quantized layers before them and can be prepared ahead, on another stream.
  */
 int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
                              float* AT, float* XT, float* nrm2, int64_t m_pad, void* stream);
+
+/*
+ * The same in ONE pass over A and X: the transposing kernel also carries every column's canonical chains of x * x, so
+ * that XT is not read again for the norms (bit-identical nrm2).  ws: gpfq_prepare_ws_bytes(D, m) bytes of device memory
+ * (one partial sum per column and 1024-sample segment), 4-byte aligned; with ws == NULL (or too small) this IS
+ * gpfq_prepare_columns_f32.
+ */
+size_t gpfq_prepare_ws_bytes(int64_t D, int64_t m);
+int gpfq_prepare_columns_ws_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
+                                float* AT, float* XT, float* nrm2, int64_t m_pad, void* ws, size_t ws_bytes, void* stream);
 
 /*
  * The GPFQ loop on one group, in place on Q and U -- replaces

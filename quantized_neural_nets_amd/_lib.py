@@ -22,7 +22,7 @@ EXPORTS = [
     "gpfq_prepare_columns_f32", "gpfq_quantization_f32", "gpfq_quantize_layer_f32", "gpfq_quantizer_f32",
     "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32", "gpfq_scratch_bytes",
     "gpfq_read_status", "gpfq_column_norms_f32", "gpfq_gather_patches_f32", "gpfq_last_launch_used_exchange",
-    "gpfq_describe_plan_mode",
+    "gpfq_describe_plan_mode", "gpfq_prepare_ws_bytes", "gpfq_prepare_columns_ws_f32",
 ]
 
 
@@ -56,6 +56,10 @@ def _load():
     lib.gpfq_workspace_bytes.argtypes = [i64, i64, i64, i32]
     lib.gpfq_prepare_columns_f32.restype = i32
     lib.gpfq_prepare_columns_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, vp, vp, i64, vp]
+    lib.gpfq_prepare_ws_bytes.restype = sz
+    lib.gpfq_prepare_ws_bytes.argtypes = [i64, i64]
+    lib.gpfq_prepare_columns_ws_f32.restype = i32
+    lib.gpfq_prepare_columns_ws_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, vp, vp, i64, vp, sz, vp]
     lib.gpfq_quantization_f32.restype = i32
     lib.gpfq_quantization_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, vp, vp, i64, i64, i64, i64,
                                           f32, i32, i32, f32, u64, u64, vp, i64, i32, vp, i32, vp, sz, vp]

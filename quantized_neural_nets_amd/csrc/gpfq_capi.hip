@@ -741,7 +741,8 @@ size_t gpfq_workspace_bytes(int64_t N, int64_t d_g, int64_t m, int groups)
 {
     (void)N;
     if (d_g < 0 || m < 0 || groups < 1) return 0;
-    return kScratchBytes + 2 * ws_cols_bytes(d_g, m, groups) + ws_nrm_bytes(d_g, groups) + 256;
+    return kScratchBytes + 2 * ws_cols_bytes(d_g, m, groups) + ws_nrm_bytes(d_g, groups) + 256 +
+           gpfq_prepare_ws_bytes(d_g * (int64_t)groups, m);                 // [scratch][AT][XT][nrm2][segment sums]
 }
 
 int gpfq_read_status(void* scratch, int* status_host4, void* stream)
@@ -763,14 +764,16 @@ int gpfq_read_status(void* scratch, int* status_host4, void* stream)
 int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
                              float* AT, float* XT, float* nrm2, int64_t m_pad, void* stream)
 {
-    if (!A || !X || !AT || !XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");
-    if (m < 0 || D < 0 || lda < D || ldx < D) return fail(GPFQ_ERR_ARG, "bad shape (need lda, ldx >= D)");
+    // one matrix only: A == NULL (AT untouched) or X == NULL (XT and nrm2 untouched) -- a caller that prepares the analog
+    // columns ahead of time, on another stream, and the quantized ones when they exist
+    if ((!A && !X) || (A && !AT) || (X && (!XT || !nrm2))) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (m < 0 || D < 0 || (A && lda < D) || (X && ldx < D)) return fail(GPFQ_ERR_ARG, "bad shape (need lda, ldx >= D)");
     if (m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "m_pad must equal gpfq_padded_m(m)");
-    if ((reinterpret_cast<uintptr_t>(AT) & 15) || (reinterpret_cast<uintptr_t>(XT) & 15))
+    if ((A && (reinterpret_cast<uintptr_t>(AT) & 15)) || (X && (reinterpret_cast<uintptr_t>(XT) & 15)))
         return fail(GPFQ_ERR_ARG, "AT / XT must be 16-byte aligned");
     if (D == 0) return GPFQ_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (D <= 60 && lda == D && ldx == D && !env_int("GPFQ_NO_SMALL_TRANSPOSE", 0)) {      // (256 x 61 floats of LDS)
+    if (D <= 60 && (!A || lda == D) && (!X || ldx == D) && !env_int("GPFQ_NO_SMALL_TRANSPOSE", 0)) {      // (256 x 61 floats of LDS)
         // few columns of contiguous matrices (first convs, EfficientNet's narrow 1x1 convs at 112 x 112): flat reads
         const size_t shm = sizeof(float) * 256 * (size_t)((int)D | 1);
         hipLaunchKernelGGL(gpfq::gpfq_transpose_pad_small_kernel, dim3((unsigned)(m_pad / 256), 2), dim3(256), shm, st, A, X, m,
@@ -782,11 +785,73 @@ int gpfq_prepare_columns_f32(const float* A, int64_t lda, const float* X, int64_
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "transpose launch");
+    if (!X) return GPFQ_OK;
     const int S = (int)(m_pad / gpfq::kSeg);
     hipLaunchKernelGGL(gpfq::gpfq_colnorm_kernel, dim3((unsigned)D), dim3(colnorm_threads(D, S)), sizeof(float) * (size_t)S, st,
                        XT, m_pad, S, nrm2);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "colnorm launch");
+    return GPFQ_OK;
+}
+
+size_t gpfq_prepare_ws_bytes(int64_t D, int64_t m)
+{
+    if (D < 0 || m < 0) return 0;
+    const size_t S = (size_t)(gpfq_padded_m(m) / gpfq::kSeg);
+    return (((size_t)D * S * sizeof(float) + 255) / 256) * 256;          // one segment sum per (column, segment)
+}
+
+int gpfq_prepare_columns_ws_f32(const float* A, int64_t lda, const float* X, int64_t ldx, int64_t m, int64_t D,
+                                float* AT, float* XT, float* nrm2, int64_t m_pad, void* ws, size_t ws_bytes, void* stream)
+{
+    // without a workspace for the segment sums (or with the fused pass switched off): transpose, then norms from XT
+    // (the segment sums belong to X: the analog matrix alone needs no workspace)
+    if ((X && (!ws || ws_bytes < gpfq_prepare_ws_bytes(D, m))) || env_int("GPFQ_NO_FUSED_PREP", 0))
+        return gpfq_prepare_columns_f32(A, lda, X, ldx, m, D, AT, XT, nrm2, m_pad, stream);
+    if ((!A && !X) || (A && !AT) || (X && (!XT || !nrm2))) return fail(GPFQ_ERR_ARG, "null pointer");
+    if (m < 0 || D < 0 || (A && lda < D) || (X && ldx < D)) return fail(GPFQ_ERR_ARG, "bad shape (need lda, ldx >= D)");
+    if (m_pad != gpfq_padded_m(m)) return fail(GPFQ_ERR_ARG, "m_pad must equal gpfq_padded_m(m)");
+    if ((A && (reinterpret_cast<uintptr_t>(AT) & 15)) || (X && (reinterpret_cast<uintptr_t>(XT) & 15)) || (reinterpret_cast<uintptr_t>(ws) & 3))
+        return fail(GPFQ_ERR_ARG, "AT / XT must be 16-byte aligned");
+    if (D == 0) return GPFQ_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = (int)(m_pad / gpfq::kSeg);
+    const int64_t ntile64 = (D + 63) / 64;
+    if (!A) lda = ldx;                              // (the skipped matrix takes no part in the choice of the load mode)
+    if (!X) ldx = lda;
+    const bool aligned = !((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(X)) & 15);
+    const bool flat = D <= 64 && lda == D && ldx == D && aligned;
+    const bool vec = !flat && aligned && (lda & 3) == 0 && (ldx & 3) == 0 && (D & 3) == 0;
+    const int ntile = (int)ntile64;
+    const int G = ntile < 8 ? ntile : 8;            // column tiles side by side: 2 KB of every input row
+    const int64_t ngroups = (ntile + G - 1) / G;
+    const int64_t nblocks = ngroups * S * 2 * G;
+    if (nblocks > 0x7fffffffLL) return fail(GPFQ_ERR_UNSUPPORTED, "too many column tiles");
+    constexpr size_t shm = 256 * 65 * sizeof(float);
+    float* part = static_cast<float*>(ws);
+    hipError_t e;
+#define GPFQ_LAUNCH_TN(FLATV, VECV)                                                                                   \
+    {                                                                                                                 \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) {                                                                                              \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpfq::gpfq_transpose_norm_kernel<FLATV, VECV>),     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                            \
+            if (e != hipSuccess) return hip_fail(e, "dynamic LDS size");                                              \
+            attr_set = true;                                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL((gpfq::gpfq_transpose_norm_kernel<FLATV, VECV>), dim3((unsigned)nblocks), dim3(256), shm, st, A, \
+                           lda, X, ldx, m, D, AT, XT, m_pad, part, S, ntile, G);                                       \
+    }
+    if (flat) GPFQ_LAUNCH_TN(true, false)
+    else if (vec) GPFQ_LAUNCH_TN(false, true)
+    else GPFQ_LAUNCH_TN(false, false)
+#undef GPFQ_LAUNCH_TN
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "transpose + norm launch");
+    if (!X) return GPFQ_OK;
+    hipLaunchKernelGGL(gpfq::gpfq_colnorm_finish_kernel, dim3((unsigned)D), dim3(64), 0, st, part, S, nrm2);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "colnorm finish launch");
     return GPFQ_OK;
 }
 
@@ -853,7 +918,8 @@ int gpfq_quantize_layer_f32(const float* W, const float* A, int64_t lda, const f
     float* AT = reinterpret_cast<float*>(ws + kScratchBytes);
     float* XT = reinterpret_cast<float*>(ws + kScratchBytes + cb);
     float* nrm2 = reinterpret_cast<float*>(ws + kScratchBytes + 2 * cb);
-    int rc = gpfq_prepare_columns_f32(A, lda, X, ldx, m, D, AT, XT, nrm2, mp, stream);
+    char* part = ws + kScratchBytes + 2 * cb + ws_nrm_bytes(d_g, groups) + 256;
+    int rc = gpfq_prepare_columns_ws_f32(A, lda, X, ldx, m, D, AT, XT, nrm2, mp, part, gpfq_prepare_ws_bytes(D, m), stream);
     if (rc) return rc;
     return gpfq_quantize_groups_prepared_f32(W, Q, U, AT, XT, nrm2, N, d_g, m, mp, groups, step, K, mode, lamb, seed,
                                              row_id0, idx, idx_bytes, usq_seg, plan, ws, kScratchBytes, stream);

@@ -601,10 +601,24 @@ __device__ __forceinline__ int fresh_lane_id()
     return ln;
 }
 
+// A wave-uniform pointer as an SGPR pair, for the "s" base operand of the window loads.  Two HAZARDS of the gfx940 family
+// that the compiler pads for its own instructions but not across the boundary of an asm statement, which it does not
+// look into -- both met in round 3, when a change elsewhere in the kernels moved the scheduling:
+//   * an SGPR written by a VALU instruction (v_readfirstlane) may not be read by a VMEM instruction within the next 5
+//     wait states: with the readfirstlane a builtin, one build scheduled `v_readfirstlane_b32 s49, v5` directly in front
+//     of the asm `global_load_dwordx4 ..., s[48:49]`; the load went out with a stale s49 and the kernel faulted;
+//   * a VGPR written by a VALU instruction may not be read by v_readfirstlane / v_readlane in the very next wait state:
+//     with the readfirstlanes inside an asm statement and the 64-bit add that forms the pointer right in front of it,
+//     the low half came back stale (fault addresses of the form 0x7e1b00000000).
+// So the readfirstlanes, one wait state in front of them and five behind them are ONE asm statement (prologue only:
+// inside the loop the pointers advance by scalar adds, which have neither hazard), and tools/check_async_loads.py
+// rejects any build whose ISA shows either pattern around an asm statement.
 __device__ __forceinline__ const float* uniform_ptr(const float* p)
 {
     const uintptr_t v = reinterpret_cast<uintptr_t>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const unsigned vlo = (unsigned)v, vhi = (unsigned)(v >> 32);
+    unsigned lo, hi;
+    asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 4" : "=s"(lo), "=s"(hi) : "v"(vlo), "v"(vhi));
     return reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
 }
 

@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) gpfq_transpose_pad_kernel(const float* __
     const bool second = virt & 1u;                                     // X behind A of the same column tile
     const int64_t tile_y = (int64_t)gridDim.y - 1 - (virt >> 1);       // last column tile first
     const float* __restrict__ in = second ? X : A;
+    if (in == nullptr) return;                                         // (one matrix only)
     const int64_t ld = second ? ldx : lda;
     float* __restrict__ out = second ? XT : AT;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -53,6 +54,7 @@ __global__ void __launch_bounds__(256) gpfq_transpose_pad_small_kernel(const flo
 {
     extern __shared__ float tile[];                 // [256][D | 1]
     const float* __restrict__ in = blockIdx.y ? X : A;
+    if (in == nullptr) return;                      // (one matrix only)
     float* __restrict__ out = blockIdx.y ? XT : AT;
     const int ldt = D | 1;
     const int64_t k0 = (int64_t)blockIdx.x * 256;
@@ -99,6 +101,178 @@ __global__ void __launch_bounds__(1024) gpfq_colnorm_kernel(const float* __restr
             nrm2[2 * col] = n2;
             nrm2[2 * col + 1] = (n2 > 0.0f) ? 1.0f / n2 : 0.0f;      // for quant_msq_from_dot (gpfq_device.h)
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column preparation in ONE pass: transpose + pad of A and X AND the canonical sums of squares of X's columns.
+//
+// A workgroup owns (one canonical segment of 1024 samples) x (64 columns) of one matrix and walks the segment's four
+// 256-sample blocks c = 0..3 in order: block -> registers (16-byte loads) -> LDS -> out, where wave w writes columns
+// w, w + 4, ... and lane l the four samples 4l .. 4l + 3 of the block as ONE 16-byte store (a column's 256 samples are
+// 1 KB contiguous; the segment's four blocks 4 KB).  Those four samples are exactly elements e = 4c .. 4c + 3 of lane
+// l's chain in the canonical dot product (gpfq_device.h sweep16: e = 4c + j <-> k = 1024 s + 256 c + 4 l + j), so the
+// storing thread extends the column's chain acc = fma(x, x, acc) in the canonical order on its way, and after block 3
+// the wave's 64 chains go through the canonical lane tree: one segment sum per (column, segment), bit for bit what
+// gpfq_colnorm_kernel computes from XT -- which is then never read again.  gpfq_colnorm_finish_kernel runs the slot
+// tree over a column's segment sums.  (Round 2: transpose at 4.4 TB/s with 4-byte stores of 256-byte runs, then a
+// second kernel re-reading XT for the norms.)
+//
+// Dispatch order (1-D grid, x fastest): column tiles in groups of G from the LAST group down (what the Infinity Cache
+// still holds when the loop starts is the columns it needs first, see gpfq_transpose_pad_kernel); inside a group the
+// segments in order, and for each segment the group's column tiles next to each other, A and X of a tile back to
+// back: workgroups that run together read the same input rows side by side (G x 256 contiguous bytes of every row).
+// FLAT: the matrix is contiguous with few columns (lda == D <= 64: first convs, EfficientNet's narrow 1x1 convs): a
+// 256-row block is one run of 256 * D floats, read flat with 16-byte loads whatever D is.
+// VEC (tiled mode): 16-byte loads (needs ld % 4 == 0, D % 4 == 0, an aligned base); otherwise guarded 4-byte loads.
+// LDS: tile[256][65] floats (dynamic, 66 560 bytes: two workgroups per CU).
+template <bool FLAT, bool VEC>
+__global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* __restrict__ A, int64_t lda,
+                                                                  const float* __restrict__ X, int64_t ldx, int64_t m,
+                                                                  int64_t D, float* __restrict__ AT, float* __restrict__ XT,
+                                                                  int64_t m_pad, float* __restrict__ part, int S, int ntile,
+                                                                  int G)
+{
+    extern __shared__ float tile[];                 // [256][65]
+    constexpr int TS = 65;
+    // block -> (group of column tiles, segment, matrix, tile in group)
+    unsigned idx = blockIdx.x;
+    const int tig = (int)(idx % (unsigned)G); idx /= (unsigned)G;
+    const bool second = idx & 1u; idx >>= 1;
+    const int s = (int)(idx % (unsigned)S);
+    const int grp = (int)(idx / (unsigned)S);
+    const int tile_rev = grp * G + tig;
+    if (tile_rev >= ntile) return;                  // (ragged last group)
+    const int tile_y = ntile - 1 - tile_rev;
+    const float* __restrict__ in = second ? X : A;
+    if (in == nullptr) return;                      // (one matrix only: gpfq_prepare_columns_ws_f32 with A or X NULL)
+    const int64_t ld = second ? ldx : lda;
+    float* __restrict__ out = second ? XT : AT;
+    const int t0 = tile_y * 64;
+    const int ncols = (int)((D - t0) < 64 ? (D - t0) : 64);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    float4 v[16];
+    auto load_block = [&](int c) {
+        const int64_t kb = (int64_t)s * kSeg + 256 * c;
+        if constexpr (FLAT) {
+            // 256 rows x D floats, contiguous: float4 number f covers elements 4 f .. 4 f + 3 of the run
+            const int64_t valid = (m - kb < 256 ? (m - kb > 0 ? m - kb : 0) : 256) * D;    // elements of the run that exist
+            const float* __restrict__ src = in + kb * D;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t e0 = 4 * ((int64_t)tid + 256 * i);
+                float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (e0 < 256 * D) {
+                    if (e0 + 3 < valid) r = *reinterpret_cast<const float4*>(src + e0);
+                    else {
+                        if (e0 < valid) r.x = src[e0];
+                        if (e0 + 1 < valid) r.y = src[e0 + 1];
+                        if (e0 + 2 < valid) r.z = src[e0 + 2];
+                    }
+                }
+                v[i] = r;
+            }
+        } else {
+            const int c4 = (tid & 15) * 4, r0 = tid >> 4;       // 16 lanes x 16 bytes = one 256-byte row of the tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t k = kb + r0 + 16 * i;
+                float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (k < m) {
+                    const float* __restrict__ src = in + k * ld + t0 + c4;
+                    if (VEC) {
+                        if (c4 < ncols) r = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (c4 < ncols) r.x = src[0];
+                        if (c4 + 1 < ncols) r.y = src[1];
+                        if (c4 + 2 < ncols) r.z = src[2];
+                        if (c4 + 3 < ncols) r.w = src[3];
+                    }
+                }
+                v[i] = r;
+            }
+        }
+    };
+    auto stage_block = [&]() {                      // registers -> tile[k][t]
+        if constexpr (FLAT) {
+            const int Di = (int)D;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int e0 = 4 * (tid + 256 * i);
+                if (e0 < 256 * Di) {
+                    int k = e0 / Di, t = e0 - k * Di;
+                    const float el[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (k < 256) tile[k * TS + t] = el[q];
+                        if (++t == Di) { t = 0; ++k; }
+                    }
+                }
+            }
+        } else {
+            const int c4 = (tid & 15) * 4, r0 = tid >> 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float* row = tile + (r0 + 16 * i) * TS + c4;
+                row[0] = v[i].x; row[1] = v[i].y; row[2] = v[i].z; row[3] = v[i].w;
+            }
+        }
+    };
+    load_block(0);
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+        if (c > 0) __syncthreads();                 // the previous block has been read out of the tile
+        stage_block();
+        __syncthreads();
+        if (c < 3) load_block(c + 1);               // in flight while this block leaves
+        const int64_t kb = (int64_t)s * kSeg + 256 * c;
+        const float* col = tile + 4 * lane * TS;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int tt = wave + 4 * j;
+            if (tt < ncols) {                       // (wave-uniform)
+                const float x0 = col[tt], x1 = col[TS + tt], x2 = col[2 * TS + tt], x3 = col[3 * TS + tt];
+                *reinterpret_cast<float4*>(out + (int64_t)(t0 + tt) * m_pad + kb + 4 * lane) = make_float4(x0, x1, x2, x3);
+                float a = acc[j];                   // elements e = 4c .. 4c + 3 of lane `lane`'s canonical chain
+                a = __builtin_fmaf(x0, x0, a);
+                a = __builtin_fmaf(x1, x1, a);
+                a = __builtin_fmaf(x2, x2, a);
+                a = __builtin_fmaf(x3, x3, a);
+                acc[j] = a;
+            }
+        }
+    }
+    if (second) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int tt = wave + 4 * j;
+            if (tt < ncols) {
+                const float sg = wave_tree64_lane63(acc[j]);
+                if (lane == 63) part[(int64_t)(t0 + tt) * S + s] = sg;
+            }
+        }
+    }
+}
+
+// nrm2 pair of every column from its S segment sums (gpfq_transpose_norm_kernel's `part`): the canonical slot tree, the
+// second half of gpfq_colnorm_kernel.  One wave per column.
+__global__ void __launch_bounds__(64) gpfq_colnorm_finish_kernel(const float* __restrict__ part, int S, float* __restrict__ nrm2)
+{
+    const int lane = threadIdx.x;
+    const int64_t col = blockIdx.x;
+    const float* __restrict__ seg = part + col * S;
+    const int P = pow2_ceil(S);
+    const int per = P > 64 ? P / 64 : 1, nl = P > 64 ? 64 : P;
+    const SlotMap smap = make_slot_map(S, P, 0, per, lane, nl);
+    const float tot = combine_slots<true>(seg, smap, per, nl, S - 1);
+    const float r = sqrtf(tot);
+    if (lane == 0) {
+        const float n2 = r * r;
+        nrm2[2 * col] = n2;
+        nrm2[2 * col + 1] = (n2 > 0.0f) ? 1.0f / n2 : 0.0f;
     }
 }
 

@@ -19,20 +19,23 @@ _ctx = None
 
 
 class ShardContext:
-    def __init__(self, group=None, gather_residual=False):
+    def __init__(self, group=None, gather_residual=False, force=False):
         self.group = group
         self.rank = td.get_rank(group)
         self.world = td.get_world_size(group)
         self.gather_residual = gather_residual
+        self.force = force
 
 
-def enable(group=None, gather_residual=False):
+def enable(group=None, gather_residual=False, force=False):
     """Turn on neuron sharding for every following StepAlgorithm._quantize_layer call.
-    torch.distributed must be initialised (one process per GPU)."""
+    torch.distributed must be initialised (one process per GPU).
+    force: take the sharded path -- partition, all_gather of the indices, all_reduce of the partial sums -- even in a
+    world of ONE rank, where it is an identity: the way to drive the collectives through RCCL on a single GPU."""
     global _ctx
     if not td.is_available() or not td.is_initialized():
         raise RuntimeError("torch.distributed is not initialised")
-    _ctx = ShardContext(group, gather_residual)
+    _ctx = ShardContext(group, gather_residual, force)
     return _ctx
 
 
@@ -42,7 +45,7 @@ def disable():
 
 
 def active():
-    return _ctx if (_ctx is not None and _ctx.world > 1) else None
+    return _ctx if (_ctx is not None and (_ctx.world > 1 or _ctx.force)) else None
 
 
 def _ceil_div(a, b):

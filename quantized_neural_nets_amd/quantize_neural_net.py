@@ -73,6 +73,12 @@ class QuantizeNeuralNet:
         self.quantized_network_layers = []
         extract_layers(self.quantized_network, self.quantized_network_layers)
         self.plan = None            # kernel family for every layer (GPFQ_PLAN_*; None = auto) -- extra
+        # Put the ANALOG columns of layer i+1 into the kernels' layout on a side stream while the loop of layer i runs
+        # (the analog network never changes, so its input of the next layer does not depend on this layer's result): the
+        # analog forward of layer i+1 runs on the main stream right before layer i is quantized, only the short
+        # gather / transposition kernel goes to the side stream -- a long forward next to a cooperative launch would break
+        # the co-residency the cooperative plan counts on.  Same batches, same numpy draws, same results.  -- extra
+        self.prefetch_analog = True
         self.stochastic_seed_base = 0   # layer i of this run draws Philox streams keyed by base + i -- extra
         self.layer_reports = []     # per-layer dicts (index, errors, step) -- extra, not in the reference
         self.layer_indices = []     # per-layer alphabet indices + step, what packed.save() writes -- extra
@@ -84,9 +90,22 @@ class QuantizeNeuralNet:
         print(f'Layer indices to quantize {todo}')
         print(f'Total number of layers to quantize {len(todo)}')
 
+        ahead = None                 # (layer index, raw batch, hook) of the layer whose analog capture is already under way
+        side = None
+        if self.prefetch_analog and torch.cuda.is_available() and torch.device(self.device).type == 'cuda':
+            side = torch.cuda.Stream(device=self.device)
         for done, layer_idx in enumerate(todo):
             gc.collect()
-            analog_in, quantized_in = self._populate_linear_layer_input(layer_idx)
+            if ahead is not None and ahead[0] == layer_idx:
+                _, raw, save_input = ahead
+            else:
+                raw, save_input = self._capture_analog(layer_idx, None)
+            ahead = None
+            self._capture_quantized(layer_idx, raw, save_input)
+            del raw
+            analog_in, quantized_in = self._resolve(save_input.inputs[0]), self._resolve(save_input.inputs[1])
+            if side is not None and done + 1 < len(todo):
+                ahead = (todo[done + 1],) + self._capture_analog(todo[done + 1], side)
             print(f'\nQuantizing layer with index: {layer_idx}')
             print(f'Quantization progress: {done} out of {len(todo)-1}\n')
 
@@ -146,35 +165,79 @@ class QuantizeNeuralNet:
             arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else val
             np.save(os.path.join(RESULT_LOGGING_DIR, f'{tag}_{suffix}.npy'), arr)
 
+    def _make_hook(self, layer_idx):
+        analog_layer = self.analog_network_layers[layer_idx]
+        if type(analog_layer) == LINEAR_MODULE_TYPE:
+            return SaveInputMLP()
+        if type(analog_layer) == CONV2D_MODULE_TYPE:
+            return SaveInputConv2d(kernel_size=analog_layer.kernel_size, dilation=analog_layer.dilation,
+                                   padding=analog_layer.padding, stride=analog_layer.stride,
+                                   groups=analog_layer.groups, retain_rate=self.retain_rate)
+        raise TypeError(f'The layer type {type(analog_layer)} is not currently supported')
+
+    def _forward_to(self, net, layer, hook, raw_input_data):
+        handle = layer.register_forward_hook(hook)
+        try:
+            with torch.no_grad():
+                net(raw_input_data)
+        except InterruptException:
+            pass
+        finally:
+            handle.remove()
+
+    def _capture_analog(self, layer_idx, side_stream):
+        '''First half of quantize_neural_net.py:217-274: the NEXT batch of the loader through the analog network, cut at
+        the hooked layer.  side_stream: the hook puts its capture into the kernels' column layout on that stream (behind
+        the forward, which stays on the current stream).  Returns (raw batch on the device, hook).'''
+        raw_input_data, _ = next(self.data_loader_iter)
+        raw_input_data = raw_input_data.to(self.device)
+        save_input = self._make_hook(layer_idx)
+        save_input.side_stream = side_stream
+        self._forward_to(self.analog_network, self.analog_network_layers[layer_idx], save_input, raw_input_data)
+        save_input.side_stream = None
+        return raw_input_data, save_input
+
+    def _capture_quantized(self, layer_idx, raw_input_data, save_input):
+        '''Second half: the SAME batch through the partially quantized network with the SAME hook object (shared patch
+        sample).'''
+        self._forward_to(self.quantized_network, self.quantized_network_layers[layer_idx], save_input, raw_input_data)
+
+    @staticmethod
+    def _resolve(captured):
+        '''A capture made on the side stream carries the event that marks it ready: the current stream waits for it.'''
+        ev = getattr(captured, "ready_event", None)
+        if ev is not None:
+            cur = torch.cuda.current_stream(captured.device)
+            cur.wait_event(ev)
+            captured.T.record_stream(cur)
+            captured.ready_event = None
+        return captured
+
     def _populate_linear_layer_input(self, layer_idx):
         '''Inputs of layer `layer_idx` in the analog and in the (partially) quantized network for the NEXT
         batch of the loader (quantize_neural_net.py:217-274).  Both forwards are cut at the hooked layer.
         Returns (analog_layer_input, quantized_layer_input), each (m, features).'''
-        raw_input_data, _ = next(self.data_loader_iter)
-        analog_layer = self.analog_network_layers[layer_idx]
-        if type(analog_layer) == LINEAR_MODULE_TYPE:
-            save_input = SaveInputMLP()
-        elif type(analog_layer) == CONV2D_MODULE_TYPE:
-            save_input = SaveInputConv2d(kernel_size=analog_layer.kernel_size, dilation=analog_layer.dilation,
-                                         padding=analog_layer.padding, stride=analog_layer.stride,
-                                         groups=analog_layer.groups, retain_rate=self.retain_rate)
-        else:
-            raise TypeError(f'The layer type {type(analog_layer)} is not currently supported')
-
-        # the SAME hook object sees the analog net first, then the quantized net (shared patch sample)
-        with torch.no_grad():
-            for net, layer in ((self.analog_network, analog_layer),
-                               (self.quantized_network, self.quantized_network_layers[layer_idx])):
-                handle = layer.register_forward_hook(save_input)
-                try:
-                    net(raw_input_data.to(self.device))
-                except InterruptException:
-                    pass
-                finally:
-                    handle.remove()
+        raw_input_data, save_input = self._capture_analog(layer_idx, None)
+        self._capture_quantized(layer_idx, raw_input_data, save_input)
         del raw_input_data
         gc.collect()
         return (save_input.inputs[0], save_input.inputs[1])
+
+
+def _on_side_stream(side, src, make, *also):
+    """Run make() -- a short kernel that reads `src` (and `also`) and returns PreparedColumns -- on the side stream, behind
+    everything the current stream has queued (the forward that produced src); the result carries the event that marks it
+    ready (QuantizeNeuralNet._resolve)."""
+    cur = torch.cuda.current_stream(src.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = make()
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for t in (src,) + also:
+        t.record_stream(side)       # (allocated on the current stream, read on the side stream)
+    out.ready_event = ev
+    return out
 
 
 def _pair(v):
@@ -187,11 +250,15 @@ class SaveInputMLP:
 
     def __init__(self):
         self.inputs = []
+        self.side_stream = None     # set by the driver: put this capture into the column layout on that stream
 
     def __call__(self, module, module_in, module_out):
         if len(module_in) != 1:
             raise TypeError('The number of input layer is not equal to one!')
-        self.inputs.append(module_in[0])
+        x = module_in[0]
+        if self.side_stream is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+            x = _on_side_stream(self.side_stream, x, lambda: StepAlgorithm.prepare_columns(x))
+        self.inputs.append(x)
         raise InterruptException
 
 
@@ -208,6 +275,7 @@ class SaveInputConv2d:
         self.inputs = []
         self.call_count = 0
         self.rand_indices = None
+        self.side_stream = None     # set by the driver: run the patch gather of this capture on that stream
 
     def __call__(self, module, module_in, module_out):
         if len(module_in) != 1:
@@ -229,11 +297,17 @@ class SaveInputConv2d:
             m = sel.numel()
             mp = _lib.lib.gpfq_padded_m(m)
             xc = x.contiguous()
-            T = torch.empty((C * kh * kw, mp), device=x.device, dtype=torch.float32)
-            _lib.check(_lib.lib.gpfq_gather_patches_f32(
-                ctypes.c_void_p(xc.data_ptr()), B, C, H, W, kh, kw, ph, pw, dh, dw, ctypes.c_void_p(sel.data_ptr()), m,
-                ctypes.c_void_p(T.data_ptr()), mp, _lib.current_stream_ptr(x.device)))
-            self.inputs.append(PreparedColumns(T, m))
+
+            def gather():
+                T = torch.empty((C * kh * kw, mp), device=x.device, dtype=torch.float32)
+                _lib.check(_lib.lib.gpfq_gather_patches_f32(
+                    ctypes.c_void_p(xc.data_ptr()), B, C, H, W, kh, kw, ph, pw, dh, dw, ctypes.c_void_p(sel.data_ptr()), m,
+                    ctypes.c_void_p(T.data_ptr()), mp, _lib.current_stream_ptr(x.device)))
+                return PreparedColumns(T, m)
+            if self.side_stream is not None:
+                self.inputs.append(_on_side_stream(self.side_stream, xc, gather, sel))
+            else:
+                self.inputs.append(gather())
         else:
             cols = F.unfold(x, self.kernel_size, dilation=self.dilation, padding=self.padding,
                             stride=self.kernel_size)                   # (B, C*kh*kw, L)

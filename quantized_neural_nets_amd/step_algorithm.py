@@ -160,8 +160,9 @@ class StepAlgorithm:
         nrm2 = torch.empty((2 * max(d, 1),), device=dev, dtype=torch.float32)      # {norm, reciprocal} per column (ABI 3)
         st = _lib.current_stream_ptr(dev)
         scr = _lib.scratch(dev)
-        _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A), lda, _ptr(X), ldx, m, d, _ptr(AT), _ptr(XT),
-                                                     _ptr(nrm2), mp, st))
+        part = torch.empty((max(int(_lib.lib.gpfq_prepare_ws_bytes(d, m)), 4) // 4,), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.gpfq_prepare_columns_ws_f32(_ptr(A), lda, _ptr(X), ldx, m, d, _ptr(AT), _ptr(XT),
+                                                        _ptr(nrm2), mp, _ptr(part), part.numel() * 4, st))
         if seed is None:
             seed = _default_seeds.take() if mode == _lib.MODE_STOCHASTIC else 0
         plan = _lib.PLAN_AUTO if plan is None else int(plan)
@@ -189,6 +190,24 @@ class StepAlgorithm:
             Q.copy_(Qv)
         if Uv.data_ptr() != U.data_ptr():
             U.copy_(Uv)
+
+    def prepare_columns(layer_input):
+        '''An (m, D) layer input in the kernels' column layout (PreparedColumns: (D, m_pad), zero padded), on the current
+        stream.  The analog input of a layer does not depend on the layers quantized before it (only the quantized
+        network's input does), so a caller may prepare it AHEAD -- on a side stream, while the previous layer's loop
+        runs -- and hand it to _quantize_layer(_ex) in place of the matrix; the quantized input is then transposed (and
+        its column norms taken) when it exists.'''
+        if isinstance(layer_input, PreparedColumns):
+            return layer_input
+        A, lda = _rows_view(layer_input, "layer_input")
+        m, D = A.shape
+        mp = _lib.lib.gpfq_padded_m(m)
+        T = torch.empty((max(D, 1), mp), device=A.device, dtype=torch.float32)
+        if D == 0:
+            return PreparedColumns(T[:0], m)
+        _lib.check(_lib.lib.gpfq_prepare_columns_ws_f32(_ptr(A), lda, None, 0, m, D, _ptr(T), None, None, mp,
+                                                        None, 0, _lib.current_stream_ptr(A.device)))
+        return PreparedColumns(T, m)
 
     def _alphabet_step(W, step_size, boundary_idx, percentile, reg, lamb):
         '''rad = mean over neurons of the per-neuron |w| quantile; step = step_size*rad (- lamb/K for L0)
@@ -224,18 +243,21 @@ class StepAlgorithm:
             raise _lib.GpfqError("W must be (N, d)")
         W = W.contiguous()
         N, dg = W.shape
-        prepared = isinstance(analog_layer_input, PreparedColumns)
-        if prepared != isinstance(quantized_layer_input, PreparedColumns):
-            raise _lib.GpfqError("both layer inputs must be matrices or both PreparedColumns")
-        if prepared:
-            A, X = analog_layer_input, quantized_layer_input
+        # either input may already be in the kernels' column layout (PreparedColumns): both from the fused conv capture, or
+        # the analog one alone, prepared ahead of time on another stream (StepAlgorithm.prepare_columns)
+        a_prep = isinstance(analog_layer_input, PreparedColumns)
+        x_prep = isinstance(quantized_layer_input, PreparedColumns)
+        if a_prep:
+            A, lda = analog_layer_input, 0
             _lib.require_gpu_tensor(A.T, "analog_layer_input")
-            _lib.require_gpu_tensor(X.T, "quantized_layer_input")
-            lda = ldx = 0
         else:
             _lib.require_gpu_tensor(analog_layer_input, "analog_layer_input")
-            _lib.require_gpu_tensor(quantized_layer_input, "quantized_layer_input")
             A, lda = _rows_view(analog_layer_input, "analog_layer_input")
+        if x_prep:
+            X, ldx = quantized_layer_input, 0
+            _lib.require_gpu_tensor(X.T, "quantized_layer_input")
+        else:
+            _lib.require_gpu_tensor(quantized_layer_input, "quantized_layer_input")
             X, ldx = _rows_view(quantized_layer_input, "quantized_layer_input")
         mm = A.shape[0]
         if tuple(A.shape) != (mm, groups * dg) or tuple(X.shape) != tuple(A.shape):
@@ -284,17 +306,23 @@ class StepAlgorithm:
             hook = event_hook
             if hook:
                 hook("prepare_begin", (Nl, dg, mm, groups_loc))
-            if prepared:
+            def as_columns(M, name):
+                T = M.T
+                if not (T.is_contiguous() and tuple(T.shape) == (D, mp)):
+                    raise _lib.GpfqError("%s: PreparedColumns must be contiguous (D, m_pad)" % name)
+                return T
+            AT = as_columns(A_loc, "analog_layer_input") if a_prep else torch.empty((D, mp), device=dev, dtype=torch.float32)
+            XT = as_columns(X_loc, "quantized_layer_input") if x_prep else torch.empty((D, mp), device=dev, dtype=torch.float32)
+            if x_prep:
                 # columns came out of the capture kernel already transposed and padded: only the norms are missing
-                AT, XT = A_loc.T, X_loc.T
-                if not (AT.is_contiguous() and XT.is_contiguous() and AT.shape == (D, mp)):
-                    raise _lib.GpfqError("PreparedColumns must be contiguous (D, m_pad)")
                 _lib.check(_lib.lib.gpfq_column_norms_f32(_ptr(XT), D, mm, mp, _ptr(nrm2), st))
-            else:
-                AT = torch.empty((D, mp), device=dev, dtype=torch.float32)
-                XT = torch.empty((D, mp), device=dev, dtype=torch.float32)
-                _lib.check(_lib.lib.gpfq_prepare_columns_f32(_ptr(A_loc), lda_loc, _ptr(X_loc), ldx_loc, mm, D,
-                                                             _ptr(AT), _ptr(XT), _ptr(nrm2), mp, st))
+            if not (a_prep and x_prep):
+                # one pass: transpose + pad of the matrices that still need it, with the canonical column norms of X carried
+                # along (`part`: one partial sum per column and 1024-sample segment); a prepared input is skipped (NULL)
+                part = torch.empty((max(int(_lib.lib.gpfq_prepare_ws_bytes(D, mm)), 4) // 4,), device=dev, dtype=torch.float32)
+                _lib.check(_lib.lib.gpfq_prepare_columns_ws_f32(
+                    None if a_prep else _ptr(A_loc), lda_loc, None if x_prep else _ptr(X_loc), ldx_loc, mm, D,
+                    _ptr(AT), _ptr(XT), _ptr(nrm2), mp, _ptr(part), part.numel() * 4, st))
             if hook:
                 hook("loop_begin", (Nl, dg, mm, groups_loc))
             def launch(pl):

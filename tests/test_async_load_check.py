@@ -177,3 +177,35 @@ def test_lds_staged_kernel_spill_is_caught():
 def test_lds_dma_without_a_window_is_flagged_not_skipped():
     kind, problems = cal.check_kernel("k", LDS_DMA + ["\tscratch_load_dword v0, off, off", "\ts_endpgm"])
     assert kind == "lds-dma" and len(problems) == 1
+
+
+# ---- VALU-written SGPR -> asm VMEM hazard (the compiler pads it only for its own loads) -----------------------------
+def test_readfirstlane_right_before_an_asm_load_is_caught():
+    """what one build scheduled: `v_readfirstlane_b32 s49, v5` directly in front of the asm load that reads s[48:49] --
+    the load went out with a stale s49 and the kernel faulted"""
+    body = ["\tv_readfirstlane_b32 s38, v4", "\ts_addc_u32 s47, s47, s3", "\tv_readfirstlane_b32 s39, v5"] + win_load(208, 0)
+    bad = cal.valu_sgpr_hazards("k", body + ["\ts_endpgm"])
+    assert len(bad) == 2 and "reads s38 2 wait state(s)" in bad[0] and "reads s39 0 wait state(s)" in bad[1]
+    kind, problems = cal.check_kernel("k", body + ["\ts_endpgm"])
+    assert kind == "window" and len(problems) == 2
+
+
+def test_five_wait_states_clear_the_hazard():
+    ok = ["\tv_readfirstlane_b32 s38, v4", "\tv_readfirstlane_b32 s39, v5", "\ts_nop 4"] + win_load(208, 0)
+    assert cal.valu_sgpr_hazards("k", ok + ["\ts_endpgm"]) == []
+    short = ["\tv_readfirstlane_b32 s38, v4", "\tv_readfirstlane_b32 s39, v5", "\ts_nop 2"] + win_load(208, 0)
+    bad = cal.valu_sgpr_hazards("k", short + ["\ts_endpgm"])
+    assert len(bad) == 2 and "s38 4 wait" in bad[0] and "s39 3 wait" in bad[1]
+    # scalar-ALU writes have no such hazard
+    assert cal.valu_sgpr_hazards("k", ["\ts_add_u32 s38, s38, s2", "\ts_addc_u32 s39, s39, s3"] + win_load(208, 0) + ["\ts_endpgm"]) == []
+
+
+def test_hazard_is_followed_across_a_branch():
+    """a reload of a spilt SGPR (v_readlane) at the end of one block, the asm load at the top of the block it jumps to"""
+    body = ["\tv_readlane_b32 s38, v63, 3", "\tv_readlane_b32 s39, v63, 4", "\ts_branch .LBB0_5",
+            ".LBB0_4:", "\ts_nop 7", ".LBB0_5:"] + win_load(176, 0) + ["\ts_endpgm"]
+    bad = cal.valu_sgpr_hazards("k", body)
+    assert len(bad) == 2 and "s38" in bad[0] and "s39" in bad[1]
+    # the fall-through path alone (through the s_nop 7) is clean
+    clean = [b for b in body if "s_branch" not in b]
+    assert cal.valu_sgpr_hazards("k", clean) == []

@@ -88,12 +88,12 @@ def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, mode):
     from quantized_neural_nets_amd import _lib
     omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
     lmode = {"soft": _lib.MODE_SOFT, "hard": _lib.MODE_HARD, "stochastic": _lib.MODE_STOCHASTIC}[mode]
-    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (3, 3, 3212288)):   # (the last: two rows x 256 members -- a variant
-        # without a stochastic form: the plan chosen, and described, for that quantizer is the next-best cooperative pair)
+    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (3, 3, 3212288)):   # (the last: two rows x 256 members)
+        # every (rows, waves) pair is instantiated for all four quantizers (the stochastic forms of the four-row 12-wave
+        # and of the 256-member two-row kernel fit their register budgets since round 3): the plan does not depend on the
+        # quantizer, and what is described is what launches
         desc = _lib.describe_plan(N, d, m, 1, 0, lmode)
-        assert "rounds=" in desc, desc
-        if mode == "stochastic":
-            assert not desc.startswith("coop RT=2 C=256") and desc.startswith("coop"), desc
+        assert "rounds=" in desc and desc == _lib.describe_plan(N, d, m, 1, 0, _lib.MODE_MSQ), desc
         W, A, X = bw.synthetic_layer(N, d, m, 91 + N, first_layer=False)
         step = bw.layer_step(W)
         r = _run(W, A, X, m, 0, mode=mode, seed=4321, step=step)
@@ -101,6 +101,31 @@ def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, mode):
         assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
         assert np.array_equal(r["U"].cpu().numpy(), U)
         st = _run(W, A, X, m, 1, mode=mode, seed=4321, step=step)
+        assert torch.equal(st["idx"], r["idx"]) and torch.equal(st["U"], r["U"])
+
+
+def test_stochastic_forms_of_the_four_row_12_wave_and_the_256_member_two_row_kernels(oracle_mod, monkeypatch):
+    """Round 3 instantiated the two variants that had no stochastic form (their Philox rounds did not fit the register
+    budget before the rare blocks stopped keeping per-lane addresses live): four rows at 9..12 sweep waves
+    (gpfq_coop_rt4_m3_w12) and two rows on 256 members (gpfq_coop_rt2_m3_w16o), forced here, against the oracle's Philox
+    stream keyed by global rows and against the streaming plan."""
+    from quantized_neural_nets_amd import _lib
+    for (N, d, m), env, want in (((22, 7, 40000), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "4"}, "coop RT=4 C=4 waves=10 S=40"),
+                                 ((5, 3, 3212288), {"GPFQ_COOP_RT": "2", "GPFQ_COOP_C": "256"}, "coop RT=2 C=256 waves=13 S=3137")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        desc = _lib.describe_plan(N, d, m, 1, 3, _lib.MODE_STOCHASTIC)
+        assert desc.startswith(want), desc
+        W, A, X = bw.synthetic_layer(N, d, m, 303 + N, first_layer=False)
+        step = bw.layer_step(W)
+        r = _run(W, A, X, m, 3, mode="stochastic", seed=99, step=step)
+        Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8, mode=oracle_mod.MODE_STOCHASTIC,
+                                            lamb=0.05, seed=99)
+        assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
+        assert np.array_equal(r["U"].cpu().numpy(), U)
+        for k in env:
+            monkeypatch.delenv(k)
+        st = _run(W, A, X, m, 1, mode="stochastic", seed=99, step=step)
         assert torch.equal(st["idx"], r["idx"]) and torch.equal(st["U"], r["U"])
 
 

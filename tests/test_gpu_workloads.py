@@ -1,0 +1,120 @@
+"""BASELINE.json configs 1-4 as WHOLE workloads on the MI355X, each checked against the CPU oracle.
+
+`bench.py --workload X --steps 1 --warmup 0` quantizes every layer of the model (reference shapes:
+quantize_neural_net.py:136-193 visits every layer, :334-347 is the m rule) through StepAlgorithm._quantize_layer_ex exactly
+as the driver does; after the run it compares, for every DISTINCT (N, d_g, m, groups) shape of the model, the first and last
+rows x the first columns of the timed run's indices with oracle.quantization on the same inputs (`oracle_shape_check`),
+and every layer's indices with a rerun on the streaming kernel family (`output_check`).  A mismatch makes bench.py exit 3.
+
+ResNet-18 additionally runs with --force-shard: a ONE-rank `nccl` process group, so that every layer of a real model goes
+through dist.quantize_sharded -> all_gather_into_tensor(int8) -> all_reduce on the GPU -- RCCL itself, not gloo.
+ResNet-50 (54 layers; the inputs of the full layers are 10^2 GB of host randn) runs on its distinct shapes with the input
+features of each layer cut to 96 per group: N, m and groups -- hence plan, kernel variant and rounds -- are the full
+layer's."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra, timeout=850):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + list(extra)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-4000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["output_check"]["mismatches"] == 0, rec["output_check"]
+    assert rec["oracle_shape_check"]["mismatches"] == 0, rec["oracle_shape_check"]
+    assert rec["cooperative_timeouts"] == 0
+    return rec, out.stderr
+
+
+def test_resnet18_all_layers_sharded_through_rccl_world_of_one():
+    """config 1: ResNet-18, all 21 conv + fc layers, 4-bit, batch 256 -- and the collectives through RCCL."""
+    rec, err = run_bench("--workload", "r18", "--force-shard", "--backend", "nccl")
+    assert rec["config"]["layers"] == 21 and rec["config"]["weights"] == 11_678_912
+    assert "one-rank nccl group" in rec["config"]["parallelism"]
+    assert rec["oracle_shape_check"]["shapes"] == 12 and rec["oracle_shape_check"]["weights"] > 10_000
+    assert rec["output_check"]["layers"] == 21
+
+
+def test_vgg16_all_layers():
+    """config 2: VGG-16, all 16 layers, 4-bit, batch 512 (720 384-sample rows, fc6 with 25 088 columns)."""
+    rec, err = run_bench("--workload", "vgg16")
+    assert rec["config"]["layers"] == 16 and rec["config"]["weights"] == 138_344_128
+    assert rec["oracle_shape_check"]["shapes"] == 12
+    assert rec["output_check"]["layers"] >= 14          # (the two 720 384-sample convs are not rerun on the streaming plan)
+
+
+def test_efficientnet_b1_all_layers_sparse_gpfq():
+    """config 4 (one GPU's worth): EfficientNet-B1, all 116 layers, 2-bit, L1 lambda 0.1, batch 1024: depthwise convs as
+    grouped cooperative launches, squeeze-excite 1x1 convs on 1x1 maps, rows of 3.2 M samples on the whole chip."""
+    rec, err = run_bench("--workload", "effnet_b1")
+    assert rec["config"]["layers"] == 116 and "L1 lamb 0.1" in rec["config"]["workload"] and "2-bit" in rec["config"]["workload"]
+    assert rec["oracle_shape_check"]["shapes"] == 55
+    assert rec["output_check"]["layers"] >= 100
+
+
+def test_resnet50_all_distinct_layer_shapes():
+    """config 3 (one GPU's worth): every distinct layer shape of ResNet-50's 54 layers at batch 1024 -- the 1x1 convs
+    that run in rounds on the LDS-staged four-row kernels included -- with full N, m, groups and 96 input features."""
+    rec, err = run_bench("--workload", "r50_all", "--distinct-shapes", "--max-cols", "96")
+    assert rec["config"]["layers"] == 24
+    assert rec["oracle_shape_check"]["shapes"] == rec["config"]["layers"]
+    assert "gpfq_coop_rt4_m0_w16l" in rec["roofline"]["families"] or "gpfq_coop_rt4_m0_w16lq" in rec["roofline"]["families"]
+
+
+def test_sharded_path_through_rccl_equals_unsharded(tmp_path):
+    """dist.enable(force=True) in a world of one rank on the `nccl` backend: quantize_sharded's all_gather_into_tensor of
+    the int8 indices and the all_reduce of the partial sums execute in RCCL on the GPU; the result must equal the
+    unsharded one bit for bit -- rows partition, whole-groups partition (depthwise), error metrics."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as td
+import golden_inputs as gi
+from quantized_neural_nets_amd import StepAlgorithm as SA, dist as qd
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+td.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert td.get_backend() == "nccl"
+try:
+    for name in ["g2_64x147x512_msq_b4", "g2_24x96x2500_msq_b4", "g4_depthwise", "g4_groups2", "g2_16x64x96_hard_b4"]:
+        case, (W, A, X), fx, _ = gi.load_case(name)
+        K = 2 ** (case["bits"] - 1)
+        args = (torch.from_numpy(W).to(dev), torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev), A.shape[0],
+                case["scalar"] / K, K, case["percentile"], case["reg"], case["lamb"], case["groups"], False, dev)
+        qd.disable()
+        plain = SA._quantize_layer_ex(*args)
+        assert plain["rows"] is None
+        qd.enable(force=True)
+        assert qd.active() is not None and qd.active().world == 1
+        sh = SA._quantize_layer_ex(*args)
+        torch.cuda.synchronize()
+        assert sh["rows"] is not None and sh["rows"].numel() == W.shape[0]          # the sharded path ran
+        assert torch.equal(sh["idx"], plain["idx"]) and torch.equal(sh["Q"], plain["Q"]) and torch.equal(sh["U"], plain["U"]), name
+        assert np.array_equal(sh["idx"].cpu().numpy().astype(np.int16), fx["idx"]), name
+        for k in ("quantize_error", "relative_quantize_error"):
+            assert abs(float(sh[k]) - float(plain[k])) <= 1e-5 * abs(float(plain[k])), (name, k)
+    print("rccl-ok")
+finally:
+    td.destroy_process_group()
+''' % (ROOT, ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "rccl-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p

@@ -294,3 +294,57 @@ def test_division_free_msq_form_equals_the_division_form(tmp_path):
     dev = open(os.path.join(ROOT, "quantized_neural_nets_amd", "csrc", "gpfq_device.h")).read()
     host = open(os.path.join(ROOT, "quantized_neural_nets_amd", "csrc", "gpfq_capi.hip")).read()
     assert "(p.qc.Kf + 4.0f) * 0x1p-18f" in host and "0x1p-60f" in dev and "p.qc.Kf <= 1024.0f" in host
+
+
+def test_bench_oracle_shape_check_samples_rows_and_groups(oracle_mod):
+    """bench.py's oracle_shape_check on the CPU, with the oracle's own full-layer indices standing in for the GPU's: the
+    sampled rows / groups / columns must line up (0 mismatches), one check per DISTINCT shape, and a corrupted index in a
+    sampled position (last row of the last group, first column) must be found."""
+    import numpy as np
+    import torch
+    import bench
+    import bench_workload as bw
+    layers = [("a", 40, 12, 300, 1), ("a2", 40, 12, 300, 1), ("dw", 6, 5, 2000, 6), ("g2", 8, 7, 1500, 2)]
+    data, idx = [], {}
+    for li, (name, N, dg, m, groups) in enumerate(layers):
+        W, A, X = bw.synthetic_layer(N, groups * dg, m, 50 + li, rows_d=dg)
+        step = bw.layer_step(W, 1.16, 2)
+        o = oracle_mod.quantize_layer(W.numpy(), A.numpy(), X.numpy(), 1.16 / 2, 2, 1.0, "L1", 0.05, groups, step=np.float32(step))
+        data.append((name, W, A, X, step, m))
+        idx[name] = torch.from_numpy(o["idx"].astype(np.int8))
+    rec = bench.oracle_shape_check(data, layers, idx, 2, 1, 0.05, 2e9)
+    assert rec["shapes"] == 3 and rec["mismatches"] == 0 and rec["weights"] == 32 * 12 + 4 * 5 + 8 * 7     # (dw: the first two and the last two of its six groups)
+    idx["dw"][5, 0] += 1
+    rec = bench.oracle_shape_check(data, layers, idx, 2, 1, 0.05, 2e9)
+    assert rec["mismatches"] == 1 and rec["failed"] and rec["failed"][0].startswith("dw group 5")
+    # the budget bounds rows x columns x m per shape (never below 4 columns)
+    rec = bench.oracle_shape_check(data[:1], layers[:1], {"a": idx["a"]}, 2, 1, 0.05, 32 * 300 * 5)
+    assert rec["weights"] == 32 * 5 and rec["mismatches"] == 0
+
+
+def test_bench_counter_rooflines_are_bounded_and_digest_gated(tmp_path, monkeypatch):
+    """roofline_issue / the measured roofline_l2 come from a committed counter summary (tools/pmc_counters.py) ONLY when it
+    carries the digest of the kernel sources in use; the issue fraction is SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (<= 1 by
+    construction), the L2 figure TCP_TCC_READ_REQ x 128 B over the launch time measured live."""
+    import json
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    per = {"SQ_WAVES": 768.0, "SQ_WAVE_CYCLES": 1000.0e6, "SQ_ACTIVE_INST_ANY": 620.0e6, "SQ_ACTIVE_INST_VALU": 460.0e6,
+           "SQ_WAIT_ANY": 270.0e6, "SQ_WAIT_INST_ANY": 110.0e6, "SQ_INSTS_VALU": 461.0e6, "SQ_INSTS_SALU": 95.0e6,
+           "TCP_TCC_READ_REQ_sum": 226.5e6, "TCC_HIT_sum": 219.7e6, "TCC_MISS_sum": 7.3e6, "TCC_EA0_RDREQ_sum": 7.25e6}
+    kern = {"gpfq::gpfq_resident_rt2_m0_w8(gpfq::SlabParams)": {"launches": 6, "per_launch": per, "shapes": {}}}
+    (prof / "r99_pmc_counters.json").write_text(json.dumps({"source_sha256": "0" * 64, "kernels": kern}))
+    fam = {"ms": 2.244 * 3, "launches": 3}
+    got, src = bench.counter_rooflines("gpfq_resident_rt2_m0_w8", fam, "f" * 64, {"frac": 0.45})
+    assert got is None and "no counter summary for this kernel source" in src
+    got, src = bench.counter_rooflines("gpfq_resident_rt2_m0_w8", fam, "0" * 64, {"frac": 0.45})
+    assert src.endswith("r99_pmc_counters.json")
+    iss, l2 = got["issue"], got["l2"]
+    assert iss["frac"] == 0.62 and iss["valu_frac"] == 0.46 and iss["wait_frac"] == 0.27 and iss["issue_stall_frac"] == 0.11
+    assert 0.0 < iss["frac"] <= 1.0 and abs(iss["frac"] + iss["wait_frac"] + iss["issue_stall_frac"] - 1.0) < 1e-9
+    assert iss["insts_per_wave"]["valu"] == round(461.0e6 / 768, 1)
+    assert l2["measured"] and l2["request_bytes"] == 128 and l2["model"] == {"frac": 0.45}
+    assert abs(l2["achieved"] - 226.5e6 * 128 / 2.244e-3 / 1e9) < 0.1 and abs(l2["frac"] - l2["achieved"] / 34500.0) < 1e-4
+    assert abs(l2["l2_hit_rate"] - 219.7 / 227.0) < 1e-4 and l2["frac"] <= 1.0

@@ -16,6 +16,10 @@ temporary parked in the register).  This script replays the ISA of those kernels
     order; loads and stores the compiler issues itself only make the hardware wait longer);
   * any other instruction that names a register in flight -- as a source or as a destination -- is an error, and
     so is any scratch access (a spill) in such a kernel.
+  * in every checked kernel: an asm load whose scalar base was written by a VALU instruction (v_readfirstlane ...) fewer
+    than 5 wait states earlier is an error -- the hardware hazard the compiler pads only for its own loads; so is a
+    v_readfirstlane / v_readlane right behind the VALU instruction that wrote its source where the two straddle the
+    boundary of an asm statement.
 
 The unrolled loop body is replayed twice, the second time starting from the state at the bottom of the loop, so
 that registers in flight across the back edge are covered.
@@ -146,6 +150,128 @@ def replay(name, lines, inflight, problems, report):
             problems.append("%s: line %d touches register(s) in flight %s: %s" % (name, no, sorted(hit), st))
 
 
+def sregs(tok):
+    """s12 -> {12}; s[46:47] -> {46, 47}; vcc -> {"vcc"}"""
+    m = re.fullmatch(r"s(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    if tok in ("vcc", "vcc_lo", "vcc_hi"):
+        return {"vcc"}
+    return set()
+
+
+def valu_sgpr_hazards(name, lines, need=5):
+    """gfx940 family: an SGPR written by a VALU instruction (v_readfirstlane, v_readlane -- every reload of a spilt SGPR
+    is one --, a compare or carry with a scalar destination) may not be read by a VMEM instruction within the next 5
+    wait states.  The compiler pads that for the VMEM instructions it emits -- not for a load inside an asm statement,
+    which it does not look into.  Every instruction is one wait state, `s_nop N` is N + 1; an asm VMEM instruction whose
+    scalar operands include a register written by VALU fewer than `need` states ago ON ANY PATH is an error: the scan
+    follows the control flow (the "young VALU-written SGPRs" at a label are the union over its fall-through and every
+    branch to it, youngest age wins), iterated to a fixed point."""
+    insts = []          # (line number, text, in_asm)
+    in_asm = False
+    for no, ln in enumerate(lines):
+        raw = ln.strip()
+        if raw.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if raw.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        st = ln.split(";")[0].strip()
+        if not st or st.startswith("."):
+            if not re.match(r"\.LBB\d+_\d+:", st):
+                continue
+        insts.append((no, st, in_asm))
+    label_at = {st[:-1]: i for i, (no, st, a) in enumerate(insts) if st.endswith(":")}
+    entry = {}          # instruction index -> {sgpr: age} merged from branches
+    problems = {}
+
+    def merge(dst, src):
+        changed = False
+        for r, a in src.items():
+            if r not in dst or a < dst[r]:
+                dst[r] = a
+                changed = True
+        return changed
+
+    for _ in range(12):
+        changed = False
+        age = {}
+        for i, (no, st, asm) in enumerate(insts):
+            if i in entry:
+                merge(age, entry[i])
+            if st.endswith(":"):
+                continue
+            op = st.split()[0]
+            toks = re.findall(r"s\[\d+:\d+\]|\bs\d+\b|\bvcc(?:_lo|_hi)?\b", st)
+            if asm and op.startswith(("global_load", "global_store", "buffer_load", "buffer_store", "flat_load", "flat_store")):
+                for tok in toks:
+                    for r in sregs(tok):
+                        if r in age and age[r] < need:
+                            problems[(no, r)] = ("%s: line %d: asm VMEM instruction reads s%s %d wait state(s) after a VALU "
+                                                 "instruction wrote it (needs %d): %s" % (name, no, r, age[r], need, st))
+            states = int(st.split()[1]) + 1 if op == "s_nop" else 1
+            for r in list(age):
+                age[r] += states
+                if age[r] >= need:
+                    del age[r]
+            if op.startswith("v_"):
+                first = st[len(op):].split(",")[0].strip()
+                for r in sregs(first):
+                    age[r] = 0
+                if op.startswith(("v_cmp", "v_cmpx")) and op.endswith("_e32"):
+                    age["vcc"] = 0
+            if op.startswith(("s_cbranch", "s_branch")):
+                tgt = st.split()[-1]
+                if tgt in label_at:
+                    changed |= merge(entry.setdefault(label_at[tgt], {}), age)
+                if op == "s_branch":
+                    age = {}
+            elif op in ("s_endpgm", "s_setpc_b64"):
+                age = {}
+        if not changed:
+            break
+    return [problems[k] for k in sorted(problems)]
+
+
+def readlane_hazards(name, lines, need=1):
+    """gfx940 family: a VGPR written by a VALU instruction may not be read by v_readlane / v_readfirstlane in the next
+    wait state.  The compiler pads that for its own instructions; checked here wherever the pair straddles the
+    boundary of an asm statement (either instruction inside one), which the compiler does not look into.  Linear scan
+    (a branch in between is itself a wait state)."""
+    out = []
+    prev = None         # (registers written by the previous VALU instruction, in_asm) if the previous instruction was VALU
+    in_asm = False
+    for no, ln in enumerate(lines):
+        raw = ln.strip()
+        if raw.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if raw.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        st = ln.split(";")[0].strip()
+        if not st or st.startswith(".") or st.endswith(":"):
+            continue
+        op = st.split()[0]
+        if op in ("v_readfirstlane_b32", "v_readlane_b32") and prev is not None and (in_asm or prev[1]):
+            src = st[len(op):].split(",")[1].strip()
+            hit = regs_of(src) & prev[0]
+            if hit:
+                out.append("%s: line %d: %s reads v%s in the wait state after a VALU instruction wrote it, across an asm "
+                           "boundary (needs %d): %s" % (name, no, op, sorted(hit), need, st))
+        if op.startswith("v_") and not op.startswith(("v_readfirstlane", "v_readlane", "v_cmp")):
+            first = st[len(op):].split(",")[0].strip()
+            prev = (regs_of(first), in_asm)
+        else:
+            prev = None
+    return out
+
+
 def is_window_kernel(lines):
     return window_start(lines) is not None
 
@@ -172,7 +298,7 @@ def check_kernel(name, lines):
         # of the SOURCE: all window statements are `asm volatile`, which the compiler keeps in program order on every
         # path, and the vmcnt arithmetic is the parity tests' job (a linear replay of the text cannot follow these
         # kernels' spin loops).
-        return "window", window_violations(name, lines) + spills(name, lines)
+        return "window", window_violations(name, lines) + spills(name, lines) + valu_sgpr_hazards(name, lines) + readlane_hazards(name, lines)
     if asm_loads:
         problems = []
         inflight = []
@@ -182,7 +308,7 @@ def check_kernel(name, lines):
         again = []
         replay(name, lines, inflight, again, True)
         problems += [p for p in again if p not in seen and "loads into register(s) still in flight" not in p]
-        return "replay", problems
+        return "replay", problems + valu_sgpr_hazards(name, lines) + readlane_hazards(name, lines)
     if uses_lds_dma(lines):
         return "lds-dma", spills(name, lines)
     return None, []
