@@ -68,6 +68,10 @@ def parse_args():
     ap.add_argument("--force-shard", action="store_true",
                     help="with --gpus 1: initialise a ONE-rank process group on --backend (nccl = RCCL) and take the sharded "
                          "path (dist.enable(force=True)): every layer goes through all_gather_into_tensor / all_reduce on the GPU")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="PROJECTION on one GPU: give every layer only the rows rank 0 of a world of this size would own "
+                         "(dist.partition), full columns, no collective -- the per-rank step of an N-GPU run, measured; the "
+                         "JSON line is marked as a projection and its value is the whole job's weights over that time")
     ap.add_argument("--prefetch-analog", action="store_true",
                     help="prepare the ANALOG columns of layer i+1 on a side stream while the loop of layer i runs (they do not "
                          "depend on the layers quantized before; the quantized columns stay serial, as in the real driver)")
@@ -171,9 +175,9 @@ def oracle_shape_check(data, layers, gpu_idx, K, mode, lamb, budget):
     nthreads = min(os.cpu_count() or 1, 32)
     seen, nshape, checked, bad, worst = set(), 0, 0, 0, []
     t0 = time.perf_counter()
-    geom = {l[0]: l[1:5] for l in layers}
     for name, W, A, X, step, m in data:
-        N, dg, m_, groups = geom[name]
+        N, dg = W.shape                              # (the rows this run quantized: a shard of the layer with --emulate-world)
+        groups = A.shape[1] // dg
         key = (N, dg, m, groups)
         if key in seen:
             continue
@@ -220,8 +224,9 @@ def kernel_name(desc, mode=0):
             return "gpfq_coop_rt1g_m%d_w12" % mode
         if rt == 1:
             return "gpfq_coop_rt1_m%d_w%d" % (mode, 16 if (waves > 12 or int(kv.get("C", "0")) > 128) else 12)
-        if rt == 4 and waves > 12:                  # columns staged through LDS; 256 granules are gathered in fours
-            return "gpfq_coop_rt4_m%d_w16l%s" % (mode, "q" if 4 * int(kv.get("C", "0")) > 128 else "")
+        if rt == 4 and (waves > 12 or int(kv.get("C", "0")) >= 64):   # columns staged through LDS (13 sweep waves, or 64+ members)
+            c_ = int(kv.get("C", "0"))             # 256 granules are gathered in fours (q), 1024 in sixteens (h)
+            return "gpfq_coop_rt4_m%d_w16l%s" % (mode, "h" if 4 * c_ > 256 else "q" if 4 * c_ > 128 else "")
         if rt == 2 and int(kv.get("C", "0")) > 64:  # two rows on 256 members: 512 granules, gathered in eights
             return "gpfq_coop_rt2_m%d_w16o" % mode
         return "gpfq_coop_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 16 if (rt == 2 and waves > 12) else 12)
@@ -401,6 +406,7 @@ def main():
     # ---- synthetic inputs, generated on the host (identical bits on every rank), resident in HBM
     t0 = time.perf_counter()
     data = []
+    shard_groups = {}
     for li, (name, N, dg, m, groups) in enumerate(l[:5] for l in layers):
         if args.capture:
             W, fmap_a, fmap_x, geom, sel = bw.synthetic_capture_layer(layers[li], args.batch, 1234 + li)
@@ -409,6 +415,18 @@ def main():
         else:
             W, A, X = bw.synthetic_layer(N, groups * dg, m, 1234 + li, first_layer=False, rows_d=dg)
             step = bw.layer_step(W, 1.16, K)
+            if args.emulate_world > 1:
+                # rank 0's share of the layer (the step is the full layer's: every rank computes it from the full W)
+                kind_, chunk = qdist.partition(N, groups, args.emulate_world)
+                a, b = qdist.local_range(kind_, chunk, N, groups, 0)
+                if kind_ == "rows":
+                    W = W[a:b].contiguous()
+                elif kind_ == "groups":
+                    Ng = N // groups
+                    W, A, X = W[a * Ng:b * Ng].contiguous(), A[:, a * dg:b * dg].contiguous(), X[:, a * dg:b * dg].contiguous()
+                    shard_groups[name] = b - a
+                else:
+                    sys.exit("bench.py --emulate-world: layer %s would shard rows inside groups (one launch per group): not emulated" % name)
             data.append((name, W.to(dev), A.to(dev), X.to(dev), step, m))
             del A, X
         del W
@@ -421,7 +439,7 @@ def main():
     cur = {"name": None, "on": False}
     last_idx = {}
     timeouts = []
-    groups_of = {l[0]: l[4] for l in layers}
+    groups_of = {l[0]: shard_groups.get(l[0], l[4]) for l in layers}
     plan = args.plan or None
 
     def hook(tag, shape):
@@ -550,11 +568,11 @@ def main():
         if not rec:
             continue
         Nl = N
-        if world > 1:
-            kind_, chunk = qdist.partition(N, groups, world)
+        if world > 1 or args.emulate_world > 1:
+            kind_, chunk = qdist.partition(N, groups, max(world, args.emulate_world))
             a, b = qdist.local_range(kind_, chunk, N, groups, rank)
             Nl = (b - a) if kind_ == "rows" else (b - a) * (N // groups) if kind_ == "groups" else (b - a) * groups
-        gl = groups if world == 1 else max(1, min(groups, Nl))
+        gl = groups if (world == 1 and args.emulate_world <= 1) else max(1, min(groups, Nl))
         desc = _lib.describe_plan(max(Nl, 1), dg, m, gl if Nl % gl == 0 else 1, args.plan)
         kind = kernel_name(desc, mode)
         mp = _lib.lib.gpfq_padded_m(m)
@@ -638,6 +656,9 @@ def main():
             "value": round(total_weights * args.steps / elapsed / 1e6, 4),
             "unit": "M weights/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            **({"projection": "ONE GPU ran the rows rank 0 of a %d-GPU world would own (every layer, full columns, no collective): "
+                              "value = the whole job's weights over that per-rank time" % args.emulate_world,
+                "emulated_world": args.emulate_world} if args.emulate_world > 1 else {}),
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "strong",

@@ -90,7 +90,7 @@ bool coop_variant_exists(int RT, int NW, int C, int mode);
 int coop_wave_bound(int RT, int NW, int C)
 {
     if (RT == 1) return (NW <= 12 && C <= 128) ? 12 : 16;    // (16: the variant that gathers four members per lane)
-    if (RT == 4 && C == 64) return 16;                  // (256 granules: the LDS-staged variant only, up to 13 sweep waves)
+    if (RT == 4 && C >= 64) return 16;                  // (256 / 1024 granules: the LDS-staged variant only, up to 13 sweep waves)
     if (RT == 2 && C > 64) return 16;                   // (the variant that gathers eight members per lane)
     if (NW <= 8) return 8;
     if (RT == 4) return NW <= 12 ? 12 : 16;             // (16: the LDS-staged variant, 13 sweep waves)
@@ -189,12 +189,13 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
         const int64_t tiles = (Ng + RT - 1) / RT;
         // the reducer gathers RT * C <= 128 granules (two per lane) -- 256 in the one-row 16-wave variant (four per lane),
         // 512 in the two-row one (eight per lane)
-        for (int C = (RT == 4 ? 64 : 256); C >= 2; C >>= 1) {
+        for (int C = 256; C >= 2; C >>= 1) {
+            if (RT == 4 && C == 128) continue;                                     // (512 granules of four rows: no variant gathers them)
             if (force_c && C != force_c) continue;
             if (C > S || C > capacity) continue;
             const int NW = (S + C - 1) / C;
             if (RT == 1 && (C > 128 || NW > 12) && (C < 4 || NW > 15)) continue;   // (that variant gathers in fours)
-            if (RT == 4 && C == 64 && NW > 13) continue;                           // (256 granules: the LDS-staged variant only)
+            if (RT == 4 && C >= 64 && NW > 13) continue;                           // (256 / 1024 granules: the LDS-staged variant only)
             if (RT == 2 && C > 64 && NW > 15) continue;                            // (256 / 512 granules: the 16-wave variant that gathers eight members per lane, reducer wave of its own)
             if (RT == 4 && NW == 13 && env_int("GPFQ_COOP_NO_LDS", 0)) continue;
             if (NW > slab_max_waves(true, RT) || pow2_ceil_host(S) / C > 16) continue;
@@ -321,7 +322,11 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
         if (requested == GPFQ_PLAN_AUTO && groups == 1 && have_scratch && Ng > cus && !env_int("GPFQ_COOP_DISABLE", 0)) {
             Plan cp = pl;
             double ccost = 0.0;
-            if (choose_coop(Ng, pl.S, cus, mode, &cp, &ccost, false) && ccost < 0.97 * resident_step_cost(Ng, pl.S, cus)) {
+            // (the cooperative alternative may itself run in rounds where the resident plan does: 2048 rows of 13 segments
+            // are eight rounds of one-row workgroups or four of four-row tiles split in two, 9.5 vs 8.1 us per column)
+            const double rcost = resident_step_cost(Ng, pl.S, cus);
+            const bool resident_in_rounds = (Ng + pl.RT - 1) / pl.RT > (int64_t)cus * ((pl.S <= 8 ? 8 : (pl.S <= 12 ? 12 : 16)) / pl.S);
+            if (choose_coop(Ng, pl.S, cus, mode, &cp, &ccost, resident_in_rounds) && ccost < 0.97 * rcost) {
                 *out = cp;
                 return GPFQ_OK;
             }
@@ -453,13 +458,13 @@ SlabKernel coop_kernel_oct(int mode)
 }
 
 // four rows at 13 sweep waves, columns staged through LDS (gpfq_loop_kernels.h coop_lds_body)
-SlabKernel coop_kernel_lds(int mode, bool quad)
+SlabKernel coop_kernel_lds(int mode, bool quad, bool hex)
 {
     switch (mode) {
-    case gpfq::MODE_SOFT: return quad ? gpfq::gpfq_coop_rt4_m1_w16lq : gpfq::gpfq_coop_rt4_m1_w16l;
-    case gpfq::MODE_HARD: return quad ? gpfq::gpfq_coop_rt4_m2_w16lq : gpfq::gpfq_coop_rt4_m2_w16l;
-    case gpfq::MODE_STOCHASTIC: return quad ? gpfq::gpfq_coop_rt4_m3_w16lq : gpfq::gpfq_coop_rt4_m3_w16l;
-    default: return quad ? gpfq::gpfq_coop_rt4_m0_w16lq : gpfq::gpfq_coop_rt4_m0_w16l;
+    case gpfq::MODE_SOFT: return hex ? gpfq::gpfq_coop_rt4_m1_w16lh : quad ? gpfq::gpfq_coop_rt4_m1_w16lq : gpfq::gpfq_coop_rt4_m1_w16l;
+    case gpfq::MODE_HARD: return hex ? gpfq::gpfq_coop_rt4_m2_w16lh : quad ? gpfq::gpfq_coop_rt4_m2_w16lq : gpfq::gpfq_coop_rt4_m2_w16l;
+    case gpfq::MODE_STOCHASTIC: return hex ? gpfq::gpfq_coop_rt4_m3_w16lh : quad ? gpfq::gpfq_coop_rt4_m3_w16lq : gpfq::gpfq_coop_rt4_m3_w16l;
+    default: return hex ? gpfq::gpfq_coop_rt4_m0_w16lh : quad ? gpfq::gpfq_coop_rt4_m0_w16lq : gpfq::gpfq_coop_rt4_m0_w16l;
     }
 }
 
@@ -484,7 +489,7 @@ SlabKernel coop_kernel_for(int RT, int NW, int C, int mode, bool grouped, int* m
     if (maxw_out) *maxw_out = maxw;
     if (lds_out) *lds_out = lds;
     if (NW > maxw || (lds && NW > 13)) return nullptr;
-    return grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * C > 128) : oct ? coop_kernel_oct(mode) : coop_kernel(RT, mode, maxw);
+    return grouped ? coop_kernel_grouped(mode) : lds ? coop_kernel_lds(mode, RT * C > 128, RT * C > 256) : oct ? coop_kernel_oct(mode) : coop_kernel(RT, mode, maxw);
 }
 
 bool coop_variant_exists(int RT, int NW, int C, int mode)
@@ -816,35 +821,43 @@ int gpfq_prepare_columns_ws_f32(const float* A, int64_t lda, const float* X, int
     if (D == 0) return GPFQ_OK;
     hipStream_t st = (hipStream_t)stream;
     const int S = (int)(m_pad / gpfq::kSeg);
-    const int64_t ntile64 = (D + 63) / 64;
     if (!A) lda = ldx;                              // (the skipped matrix takes no part in the choice of the load mode)
     if (!X) ldx = lda;
     const bool aligned = !((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(X)) & 15);
     const bool flat = D <= 64 && lda == D && ldx == D && aligned;
     const bool vec = !flat && aligned && (lda & 3) == 0 && (ldx & 3) == 0 && (D & 3) == 0;
-    const int ntile = (int)ntile64;
-    const int G = ntile < 8 ? ntile : 8;            // column tiles side by side: 2 KB of every input row
+    // columns per workgroup: 64 (two workgroups per CU) where there are workgroups enough to balance over the chip,
+    // else 32 (four per CU, twice as many of them)
+    const int cus = device_cu_count();
+    const int64_t wg64 = (int64_t)S * ((D + 63) / 64) * ((A ? 1 : 0) + (X ? 1 : 0));
+    int TC = env_int("GPFQ_PREP_TC", 0);
+    if (TC != 32 && TC != 64) TC = (flat || wg64 >= 16 * (int64_t)cus) ? 64 : 32;
+    if (flat) TC = 64;
+    const int ntile = (int)((D + TC - 1) / TC);
+    const int G = ntile < 512 / TC ? ntile : 512 / TC;      // column tiles side by side: 2 KB of every input row
     const int64_t ngroups = (ntile + G - 1) / G;
     const int64_t nblocks = ngroups * S * 2 * G;
     if (nblocks > 0x7fffffffLL) return fail(GPFQ_ERR_UNSUPPORTED, "too many column tiles");
-    constexpr size_t shm = 256 * 65 * sizeof(float);
+    const size_t shm = 256 * (size_t)(TC + 1) * sizeof(float);
     float* part = static_cast<float*>(ws);
     hipError_t e;
-#define GPFQ_LAUNCH_TN(FLATV, VECV)                                                                                   \
+#define GPFQ_LAUNCH_TN(FLATV, VECV, TCV)                                                                              \
     {                                                                                                                 \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) {                                                                                              \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpfq::gpfq_transpose_norm_kernel<FLATV, VECV>),     \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpfq::gpfq_transpose_norm_kernel<FLATV, VECV, TCV>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                            \
             if (e != hipSuccess) return hip_fail(e, "dynamic LDS size");                                              \
             attr_set = true;                                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL((gpfq::gpfq_transpose_norm_kernel<FLATV, VECV>), dim3((unsigned)nblocks), dim3(256), shm, st, A, \
-                           lda, X, ldx, m, D, AT, XT, m_pad, part, S, ntile, G);                                       \
+        hipLaunchKernelGGL((gpfq::gpfq_transpose_norm_kernel<FLATV, VECV, TCV>), dim3((unsigned)nblocks), dim3(256), shm, st, \
+                           A, lda, X, ldx, m, D, AT, XT, m_pad, part, S, ntile, G);                                    \
     }
-    if (flat) GPFQ_LAUNCH_TN(true, false)
-    else if (vec) GPFQ_LAUNCH_TN(false, true)
-    else GPFQ_LAUNCH_TN(false, false)
+    if (flat) GPFQ_LAUNCH_TN(true, false, 64)
+    else if (vec && TC == 64) GPFQ_LAUNCH_TN(false, true, 64)
+    else if (vec) GPFQ_LAUNCH_TN(false, true, 32)
+    else if (TC == 64) GPFQ_LAUNCH_TN(false, false, 64)
+    else GPFQ_LAUNCH_TN(false, false, 32)
 #undef GPFQ_LAUNCH_TN
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "transpose + norm launch");

@@ -125,7 +125,8 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 // QUAD: the one-row 16-wave variant gathers FOUR members per lane (4j .. 4j+3: two levels of the tree over the members in
 // the lane), so that up to 256 members -- a whole chip for one row of up to 4096 segments -- fit the 64 lanes.  With two
 // rows (256 members x 2 rows = 512 granules) a lane gathers EIGHT members, 8j .. 8j+7, three levels in the lane.
-template <int RT, int MODE, bool FAST, bool ABORTWORD, bool QUAD = false>
+// GOVR (QUAD only) overrides the members per lane: 16 for FOUR rows on 256 members (1024 granules, four batches of four).
+template <int RT, int MODE, bool FAST, bool ABORTWORD, bool QUAD = false, int GOVR = 0>
 __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int lane, int tile, int c, int C, int par,
                                         int t, float n2cur, float in2cur, int row0, int64_t grow0, int seg_lo, bool gave_up)
@@ -143,7 +144,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
     // are gathered two members per lane, 2j and 2j+1 -- adjacent member blocks, the pair the first level of the tree
     // over the members adds anyway.
     static_assert(!QUAD || RT == 1 || RT == 2 || RT == 4, "four (two rows: eight) members per lane");
-    constexpr int G = RT == 2 ? 8 : 4;       // QUAD: members per lane
+    constexpr int G = GOVR ? GOVR : (RT == 2 ? 8 : 4);       // QUAD: members per lane
     const bool wide = !QUAD && RT * C > 64;
     const int per_row = QUAD ? C / G : (wide ? C >> 1 : C);  // lanes per row
     const int sh = per_row <= 16 ? 4 : (per_row <= 32 ? 5 : 6);   // log2 of the lane stride of a row in the gather
@@ -182,6 +183,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
             float v4 = 0.0f;
             for (;;) {
                 unsigned long long ok = ~0ull;
+                float vq[G / 4];                     // the lane's members in fours: the tree over them stays balanced
 #pragma unroll
                 for (int b = 0; b < G / 4; ++b) {
 #pragma unroll
@@ -189,11 +191,13 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                         g[i] = __hip_atomic_load(src + (4 * b + i) * RT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (idle lanes: granules 0 .. G-1, in bounds: C >= G)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64((unsigned)(g[i] >> 32) == epoch);
-                    const float vb = (__uint_as_float((unsigned)g[0]) + __uint_as_float((unsigned)g[1])) +
-                                     (__uint_as_float((unsigned)g[2]) + __uint_as_float((unsigned)g[3]));
-                    v4 = b == 0 ? vb : v4 + vb;
-                    if constexpr (G == 8) __builtin_amdgcn_sched_barrier(0);
+                    vq[b] = (__uint_as_float((unsigned)g[0]) + __uint_as_float((unsigned)g[1])) +
+                            (__uint_as_float((unsigned)g[2]) + __uint_as_float((unsigned)g[3]));
+                    if constexpr (G >= 8) __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (G == 4) v4 = vq[0];
+                else if constexpr (G == 8) v4 = vq[0] + vq[1];
+                else v4 = (vq[0] + vq[1]) + (vq[2] + vq[3]);
                 if ((ok | idle) == __builtin_amdgcn_read_exec()) break;
                 if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
@@ -637,7 +641,7 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
 // buffers (x ring of two, a), one step ahead (column t+1 is requested when sweep t has read its buffers for the last
 // time and has the whole exchange to land), and the sweep reads them back 16 bytes per lane per quarter (conflict-free).
 // 13 x 12 KB = 156 of the CU's 160 KB.  Same arithmetic, same order: the interleaved pair sweep, a quarter at a time.
-template <int MODE, bool QUAD>
+template <int MODE, bool QUAD, int GOVR = 0>
 __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
 {
     constexpr int RT = 4, U0 = 64;                  // window = the four residual rows only (two interleaved pairs)
@@ -775,8 +779,8 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
         for (int r = 0; r < RT; ++r) wn[r] = sload(wrow[r], 4u * (unsigned)tn);
         const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
         if (wave == rwave)
-            gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
-                                                                                n2cur, in2cur, row0, grow0, seg_lo, gave_up);
+            gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD, GOVR>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
+                                                                                      n2cur, in2cur, row0, grow0, seg_lo, gave_up);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];
@@ -810,15 +814,19 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
     finish_row_w<U0 + 33, 0, 2, false>(p, qprev[3], row0 + 3 < p.Ng, grow0 + 3, myseg, lane);
 }
 
-#define GPFQ_DEFINE_COOP_LDS(MODE, QUADV, SUFFIX)                                                                 \
+#define GPFQ_DEFINE_COOP_LDS(MODE, QUADV, GOVRV, SUFFIX)                                                          \
     __global__ void __launch_bounds__(64 * 16) __attribute__((amdgpu_num_vgpr(64 / 2)))                            \
     gpfq_coop_rt4_m##MODE##_w16##SUFFIX(const SlabParams p)                                                       \
     {                                                                                                             \
         asm volatile("" ::: "v127");                                                                              \
-        coop_lds_body<MODE, QUADV>(p);                                                                            \
+        coop_lds_body<MODE, QUADV, GOVRV>(p);                                                                     \
     }
-GPFQ_DEFINE_COOP_LDS(0, false, l) GPFQ_DEFINE_COOP_LDS(1, false, l) GPFQ_DEFINE_COOP_LDS(2, false, l) GPFQ_DEFINE_COOP_LDS(3, false, l)
-GPFQ_DEFINE_COOP_LDS(0, true, lq) GPFQ_DEFINE_COOP_LDS(1, true, lq) GPFQ_DEFINE_COOP_LDS(2, true, lq) GPFQ_DEFINE_COOP_LDS(3, true, lq)
+GPFQ_DEFINE_COOP_LDS(0, false, 0, l) GPFQ_DEFINE_COOP_LDS(1, false, 0, l) GPFQ_DEFINE_COOP_LDS(2, false, 0, l) GPFQ_DEFINE_COOP_LDS(3, false, 0, l)
+GPFQ_DEFINE_COOP_LDS(0, true, 0, lq) GPFQ_DEFINE_COOP_LDS(1, true, 0, lq) GPFQ_DEFINE_COOP_LDS(2, true, 0, lq) GPFQ_DEFINE_COOP_LDS(3, true, 0, lq)
+// four rows on 256 members (1024 granules, sixteen gathered per lane): rows so long that one row tile takes the whole chip
+// (EfficientNet-B1's 112 x 112 maps at batch 1024: 3137 segments) pull every column pair from HBM once per ROW TILE --
+// four rows per pass halve that traffic against the two-row 256-member kernel (gpfq_coop_rt2_*_w16o)
+GPFQ_DEFINE_COOP_LDS(0, true, 16, lh) GPFQ_DEFINE_COOP_LDS(1, true, 16, lh) GPFQ_DEFINE_COOP_LDS(2, true, 16, lh) GPFQ_DEFINE_COOP_LDS(3, true, 16, lh)
 
 // One __global__ per (rows per workgroup, quantizer, wave bound): see GPFQ_DEFINE_RESIDENT below for the attribute.
 #define GPFQ_DEFINE_COOP(RT, MODE, MAXW, DEPTH, WB, LAST)                                                         \

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(1024) gpfq_colnorm_kernel(const float* __restr
 // storing thread extends the column's chain acc = fma(x, x, acc) in the canonical order on its way, and after block 3
 // the wave's 64 chains go through the canonical lane tree: one segment sum per (column, segment), bit for bit what
 // gpfq_colnorm_kernel computes from XT -- which is then never read again.  gpfq_colnorm_finish_kernel runs the slot
-// tree over a column's segment sums.  (Round 2: transpose at 4.4 TB/s with 4-byte stores of 256-byte runs, then a
+// tree over a column's segment sums.  (Non-temporal loads / stores change nothing measurable: +-3 % on the HBM-bound shapes.)  (Round 2: transpose at 4.4 TB/s with 4-byte stores of 256-byte runs, then a
 // second kernel re-reading XT for the norms.)
 //
 // Dispatch order (1-D grid, x fastest): column tiles in groups of G from the LAST group down (what the Infinity Cache
@@ -125,16 +125,21 @@ __global__ void __launch_bounds__(1024) gpfq_colnorm_kernel(const float* __restr
 // FLAT: the matrix is contiguous with few columns (lda == D <= 64: first convs, EfficientNet's narrow 1x1 convs): a
 // 256-row block is one run of 256 * D floats, read flat with 16-byte loads whatever D is.
 // VEC (tiled mode): 16-byte loads (needs ld % 4 == 0, D % 4 == 0, an aligned base); otherwise guarded 4-byte loads.
-// LDS: tile[256][65] floats (dynamic, 66 560 bytes: two workgroups per CU).
-template <bool FLAT, bool VEC>
+// TC = columns per workgroup: 64 (tile[256][65] floats of dynamic LDS, 66 560 bytes: two workgroups per CU) or 32
+// (33 792 bytes: four per CU, half the work per workgroup -- twice as many workgroups to balance over the chip).
+template <bool FLAT, bool VEC, int TC>
 __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* __restrict__ A, int64_t lda,
                                                                   const float* __restrict__ X, int64_t ldx, int64_t m,
                                                                   int64_t D, float* __restrict__ AT, float* __restrict__ XT,
                                                                   int64_t m_pad, float* __restrict__ part, int S, int ntile,
                                                                   int G)
 {
-    extern __shared__ float tile[];                 // [256][65]
-    constexpr int TS = 65;
+    static_assert(TC == 64 || TC == 32, "columns per workgroup");
+    extern __shared__ float tile[];                 // [256][TC + 1]
+    constexpr int TS = TC + 1;
+    constexpr int NV = TC / 4;                      // 16-byte loads per thread and block: 256 rows x TC columns / 256 threads
+    constexpr int LPR = TC / 4;                     // lanes per row of the tile (16 bytes each)
+    constexpr int NJ = TC / 4;                      // columns per wave
     // block -> (group of column tiles, segment, matrix, tile in group)
     unsigned idx = blockIdx.x;
     const int tig = (int)(idx % (unsigned)G); idx /= (unsigned)G;
@@ -148,13 +153,13 @@ __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* _
     if (in == nullptr) return;                      // (one matrix only: gpfq_prepare_columns_ws_f32 with A or X NULL)
     const int64_t ld = second ? ldx : lda;
     float* __restrict__ out = second ? XT : AT;
-    const int t0 = tile_y * 64;
-    const int ncols = (int)((D - t0) < 64 ? (D - t0) : 64);
+    const int t0 = tile_y * TC;
+    const int ncols = (int)((D - t0) < TC ? (D - t0) : TC);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float acc[16];
+    float acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-    float4 v[16];
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.0f;
+    float4 v[NV];
     auto load_block = [&](int c) {
         const int64_t kb = (int64_t)s * kSeg + 256 * c;
         if constexpr (FLAT) {
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* _
             const int64_t valid = (m - kb < 256 ? (m - kb > 0 ? m - kb : 0) : 256) * D;    // elements of the run that exist
             const float* __restrict__ src = in + kb * D;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int64_t e0 = 4 * ((int64_t)tid + 256 * i);
                 float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (e0 < 256 * D) {
@@ -176,10 +181,10 @@ __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* _
                 v[i] = r;
             }
         } else {
-            const int c4 = (tid & 15) * 4, r0 = tid >> 4;       // 16 lanes x 16 bytes = one 256-byte row of the tile
+            const int c4 = (tid % LPR) * 4, r0 = tid / LPR;     // LPR lanes x 16 bytes = one row of the tile
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t k = kb + r0 + 16 * i;
+            for (int i = 0; i < NV; ++i) {
+                const int64_t k = kb + r0 + (256 / LPR) * i;
                 float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (k < m) {
                     const float* __restrict__ src = in + k * ld + t0 + c4;
@@ -200,23 +205,23 @@ __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* _
         if constexpr (FLAT) {
             const int Di = (int)D;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int e0 = 4 * (tid + 256 * i);
                 if (e0 < 256 * Di) {
                     int k = e0 / Di, t = e0 - k * Di;
                     const float el[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (k < 256) tile[k * TS + t] = el[q];
+                        tile[k * TS + t] = el[q];
                         if (++t == Di) { t = 0; ++k; }
                     }
                 }
             }
         } else {
-            const int c4 = (tid & 15) * 4, r0 = tid >> 4;
+            const int c4 = (tid % LPR) * 4, r0 = tid / LPR;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float* row = tile + (r0 + 16 * i) * TS + c4;
+            for (int i = 0; i < NV; ++i) {
+                float* row = tile + (r0 + (256 / LPR) * i) * TS + c4;
                 row[0] = v[i].x; row[1] = v[i].y; row[2] = v[i].z; row[3] = v[i].w;
             }
         }
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* _
         const int64_t kb = (int64_t)s * kSeg + 256 * c;
         const float* col = tile + 4 * lane * TS;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int tt = wave + 4 * j;
             if (tt < ncols) {                       // (wave-uniform)
                 const float x0 = col[tt], x1 = col[TS + tt], x2 = col[2 * TS + tt], x3 = col[3 * TS + tt];
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* _
     }
     if (second) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int tt = wave + 4 * j;
             if (tt < ncols) {
                 const float sg = wave_tree64_lane63(acc[j]);

@@ -73,12 +73,15 @@ class QuantizeNeuralNet:
         self.quantized_network_layers = []
         extract_layers(self.quantized_network, self.quantized_network_layers)
         self.plan = None            # kernel family for every layer (GPFQ_PLAN_*; None = auto) -- extra
-        # Put the ANALOG columns of layer i+1 into the kernels' layout on a side stream while the loop of layer i runs
-        # (the analog network never changes, so its input of the next layer does not depend on this layer's result): the
-        # analog forward of layer i+1 runs on the main stream right before layer i is quantized, only the short
+        # Optional: put the ANALOG columns of layer i+1 into the kernels' layout on a side stream while the loop of layer i
+        # runs (the analog network never changes, so its input of the next layer does not depend on this layer's result):
+        # the analog forward of layer i+1 runs on the main stream right before layer i is quantized, only the short
         # gather / transposition kernel goes to the side stream -- a long forward next to a cooperative launch would break
-        # the co-residency the cooperative plan counts on.  Same batches, same numpy draws, same results.  -- extra
-        self.prefetch_analog = True
+        # the co-residency the cooperative plan counts on.  Same batches, same numpy draws, same results.  OFF by default:
+        # measured (bench.py --prefetch-analog, one GPU and the per-rank shapes of 2 / 4 / 8 GPUs alike) the loop kernels are
+        # latency chains that lose more to a concurrent transposition than the overlap returns (330 -> 320 M weights/s on
+        # the headline, 422 -> 362 on an 8-GPU rank's rows).  -- extra
+        self.prefetch_analog = False
         self.stochastic_seed_base = 0   # layer i of this run draws Philox streams keyed by base + i -- extra
         self.layer_reports = []     # per-layer dicts (index, errors, step) -- extra, not in the reference
         self.layer_indices = []     # per-layer alphabet indices + step, what packed.save() writes -- extra

@@ -115,7 +115,7 @@ def test_the_built_isa_passes():
         if ("gpfq_resident_" in name or "gpfq_coop_" in name) and kind != "window":
             unguarded.append(name)
     assert checked >= 100 and bad == [] and unguarded == []
-    assert sum(1 for n in kernels if "w16l" in n) == 8          # the LDS-staged family is in the ISA that was checked
+    assert sum(1 for n in kernels if "w16l" in n) == 12         # the LDS-staged family (l, lq, lh x four quantizers) was checked
     assert not any(ln.strip().startswith("scratch_") for lines in kernels.values() for ln in lines)   # no kernel spills
 
 

@@ -13,8 +13,12 @@ import golden_inputs as gi
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("prefetch", [False, True], ids=["serial", "analog_one_layer_ahead"])
 @pytest.mark.parametrize("ci", [0, 1, 2])
-def test_quantize_network_matches_reference(ci, capsys):
+def test_quantize_network_matches_reference(ci, prefetch, capsys):
+    """... and with the analog capture of layer i+1 put into the column layout on a side stream while layer i is
+    quantized (prefetch_analog: same batches, same numpy draws, mixed prepared / matrix inputs for Linear layers): the
+    same bits."""
     from quantized_neural_nets_amd import QuantizeNeuralNet
     fx = np.load(os.path.join(gi.GOLDEN_DIR, "g5_driver.npz"))
     meta = json.loads(str(fx["meta"]))["configs"][ci]
@@ -30,6 +34,8 @@ def test_quantize_network_matches_reference(ci, capsys):
                               ignore_layers=[], mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16,
                               mlp_percentile=1, cnn_percentile=1, reg=cfg["reg"], lamb=cfg["lamb"],
                               retain_rate=cfg["retain_rate"], stochastic_quantization=False, device=dev)
+    assert quant.prefetch_analog is False            # (off by default: measured slower)
+    quant.prefetch_analog = prefetch
     qnet = quant.quantize_network()
     assert qnet is quant.quantized_network and len(quant.quantized_network_layers) == meta["nlayers"]
     for li, layer in enumerate(quant.quantized_network_layers):

@@ -51,8 +51,13 @@ CASES = [
      "128 members of one row (EfficientNet-B1's first conv at batch 1024): 64 lanes x 2 granules, two rows per round"),
     ((3, 4, 3212288), {"GPFQ_COOP_RT": "1"}, "coop RT=1 C=256 waves=13 S=3137 grid=256 rounds=3",
      "one row on the whole chip (EfficientNet-B1's 112 x 112 maps): 256 members, four gathered per lane, 13 sweep waves"),
-    ((5, 4, 3212288), {}, "coop RT=2 C=256 waves=13 S=3137 grid=256 rounds=3",
+    ((5, 4, 3212288), {"GPFQ_COOP_RT": "2", "GPFQ_COOP_C": "256", "plan": "3"}, "coop RT=2 C=256 waves=13 S=3137 grid=256 rounds=3",
      "two rows on the whole chip: 512 granules, eight gathered per lane in two batches; the last tile has one valid row"),
+    ((9, 3, 3212288), {}, "coop RT=4 C=256 waves=13 S=3137 grid=256 rounds=3",
+     "FOUR rows on the whole chip (round 3): 1024 granules, sixteen gathered per lane in four batches, columns through LDS; "
+     "the last tile has one valid row"),
+    ((6, 5, 1100000), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "256", "plan": "3"}, "coop RT=4 C=256 waves=5 S=1075 grid=256 rounds=2",
+     "the same variant with five sweep waves per member and an idle upper half of the slot tree (1075 of 2048 slots)"),
     ((5, 4, 300000), {"GPFQ_COOP_RT": "1", "GPFQ_COOP_C": "256", "plan": "3"}, "coop RT=1 C=256 waves=2 S=293 grid=256 rounds=5",
      "the same variant with two sweep waves per member and an idle upper half of the slot tree (293 of 512 slots)"),
 ]

@@ -78,8 +78,10 @@ def test_plan_selection(lib):
     assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=4 C=4 waves=13 S=50 grid=256 rounds=8")
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=16 waves=13 S=197 grid=256 rounds=16")
     assert lib.describe_plan(256, 64, 803840).startswith("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16")    # 256 granules
-    assert lib.describe_plan(2048, 512, 13312).startswith("resident RT=1 waves=13")     # <= 16 segments: whole rows, no exchange
-    assert lib.describe_plan(16, 32, 3212288).startswith("coop RT=2 C=256 waves=13 S=3137 grid=256 rounds=8")    # two rows on the whole chip
+    assert lib.describe_plan(256, 512, 13312).startswith("resident RT=1 waves=13")      # <= 16 segments, one round: whole rows, no exchange
+    assert lib.describe_plan(16, 32, 3212288).startswith("coop RT=4 C=256 waves=13 S=3137 grid=256 rounds=4")    # four rows on the whole chip (1024 granules)
+    assert lib.describe_plan(2, 32, 3212288).startswith("coop RT=2 C=256 waves=13 S=3137 grid=256 d=32")           # two rows: the 512-granule kernel
+    assert lib.describe_plan(2048, 512, 13312).startswith("coop RT=4 C=2 waves=7 S=13 grid=256 rounds=4")          # cooperative rounds against resident rounds
     assert lib.describe_plan(1, 32, 3212288).startswith("coop RT=1 C=256 waves=13 S=3137 grid=256 d=32")         # one row on the whole chip
     assert lib.describe_plan(4, 8, 4194304).startswith("stream")                        # 4096 segments: beyond 256 members x 15
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
