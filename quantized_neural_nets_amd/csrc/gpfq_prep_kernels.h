@@ -127,6 +127,45 @@ __global__ void __launch_bounds__(1024) gpfq_colnorm_kernel(const float* __restr
 // VEC (tiled mode): 16-byte loads (needs ld % 4 == 0, D % 4 == 0, an aligned base); otherwise guarded 4-byte loads.
 // TC = columns per workgroup: 64 (tile[256][65] floats of dynamic LDS, 66 560 bytes: two workgroups per CU) or 32
 // (33 792 bytes: four per CU, half the work per workgroup -- twice as many workgroups to balance over the chip).
+// The second half of a block of the one-pass kernels: a 256-sample x TC-column tile leaves LDS.  Wave w writes columns
+// w, w + 4, ..., lane l the four samples 4l .. 4l + 3 as one 16-byte store, and extends lane l's canonical chain of the
+// column by exactly those four elements (e = 4c .. 4c + 3), in order.
+template <int TC>
+__device__ __forceinline__ void prep_store_block(const float* tile, float* __restrict__ out, int t0, int ncols, int64_t m_pad,
+                                                 int64_t kb, int wave, int lane, float (&acc)[TC / 4])
+{
+    constexpr int TS = TC + 1;
+    const float* col = tile + 4 * lane * TS;
+#pragma unroll
+    for (int j = 0; j < TC / 4; ++j) {
+        const int tt = wave + 4 * j;
+        if (tt < ncols) {                           // (wave-uniform)
+            const float x0 = col[tt], x1 = col[TS + tt], x2 = col[2 * TS + tt], x3 = col[3 * TS + tt];
+            *reinterpret_cast<float4*>(out + (int64_t)(t0 + tt) * m_pad + kb + 4 * lane) = make_float4(x0, x1, x2, x3);
+            float a = acc[j];
+            a = __builtin_fmaf(x0, x0, a);
+            a = __builtin_fmaf(x1, x1, a);
+            a = __builtin_fmaf(x2, x2, a);
+            a = __builtin_fmaf(x3, x3, a);
+            acc[j] = a;
+        }
+    }
+}
+// ... and behind the segment's fourth block the wave's 64 chains of every column go through the canonical lane tree
+template <int TC>
+__device__ __forceinline__ void prep_store_sums(float* __restrict__ part, int t0, int ncols, int S, int s, int wave, int lane,
+                                                const float (&acc)[TC / 4])
+{
+#pragma unroll
+    for (int j = 0; j < TC / 4; ++j) {
+        const int tt = wave + 4 * j;
+        if (tt < ncols) {
+            const float sg = wave_tree64_lane63(acc[j]);
+            if (lane == 63) part[(int64_t)(t0 + tt) * S + s] = sg;
+        }
+    }
+}
+
 template <bool FLAT, bool VEC, int TC>
 __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* __restrict__ A, int64_t lda,
                                                                   const float* __restrict__ X, int64_t ldx, int64_t m,
@@ -233,33 +272,9 @@ __global__ void __launch_bounds__(256) gpfq_transpose_norm_kernel(const float* _
         stage_block();
         __syncthreads();
         if (c < 3) load_block(c + 1);               // in flight while this block leaves
-        const int64_t kb = (int64_t)s * kSeg + 256 * c;
-        const float* col = tile + 4 * lane * TS;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int tt = wave + 4 * j;
-            if (tt < ncols) {                       // (wave-uniform)
-                const float x0 = col[tt], x1 = col[TS + tt], x2 = col[2 * TS + tt], x3 = col[3 * TS + tt];
-                *reinterpret_cast<float4*>(out + (int64_t)(t0 + tt) * m_pad + kb + 4 * lane) = make_float4(x0, x1, x2, x3);
-                float a = acc[j];                   // elements e = 4c .. 4c + 3 of lane `lane`'s canonical chain
-                a = __builtin_fmaf(x0, x0, a);
-                a = __builtin_fmaf(x1, x1, a);
-                a = __builtin_fmaf(x2, x2, a);
-                a = __builtin_fmaf(x3, x3, a);
-                acc[j] = a;
-            }
-        }
+        prep_store_block<TC>(tile, out, t0, ncols, m_pad, (int64_t)s * kSeg + 256 * c, wave, lane, acc);
     }
-    if (second) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int tt = wave + 4 * j;
-            if (tt < ncols) {
-                const float sg = wave_tree64_lane63(acc[j]);
-                if (lane == 63) part[(int64_t)(t0 + tt) * S + s] = sg;
-            }
-        }
-    }
+    if (second) prep_store_sums<TC>(part, t0, ncols, S, s, wave, lane, acc);
 }
 
 // nrm2 pair of every column from its S segment sums (gpfq_transpose_norm_kernel's `part`): the canonical slot tree, the

@@ -93,7 +93,7 @@ def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, mode):
     from quantized_neural_nets_amd import _lib
     omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
     lmode = {"soft": _lib.MODE_SOFT, "hard": _lib.MODE_HARD, "stochastic": _lib.MODE_STOCHASTIC}[mode]
-    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (3, 3, 3212288)):   # (the last: two rows x 256 members)
+    for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (9, 3, 3212288)):   # (the last: four rows x 256 members, three rounds)
         # every (rows, waves) pair is instantiated for all four quantizers (the stochastic forms of the four-row 12-wave
         # and of the 256-member two-row kernel fit their register budgets since round 3): the plan does not depend on the
         # quantizer, and what is described is what launches
