@@ -177,6 +177,14 @@ int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, f
                        const float* uniform, float* out, int32_t* idx, void* stream);
 
 /*
+ * The uniform draws GPFQ_MODE_STOCHASTIC takes inside the loop kernels, on their own: out[i] = U[0,1) of the
+ * counter-based generator at (seed, row row_id0 + i, column) -- pass them as `uniform` to gpfq_quantizer_f32 to quantize
+ * the projections of one column exactly as the loop does at that step (step_algorithm.py:27-35 draws from torch's global
+ * CPU stream instead, which no GPU path can reproduce).
+ */
+int gpfq_philox_uniform_f32(uint64_t seed, uint64_t row_id0, uint64_t column, int64_t n, float* out, void* stream);
+
+/*
  * nrm2[2t] = ||column t||_2 ** 2 and nrm2[2t + 1] = its reciprocal (nrm2 [2 * D]), of columns that are already in the
  * prepared layout XT [D][m_pad] (step_algorithm.py:142), canonical reduction order -- the norm half of gpfq_prepare_columns_f32.
  */

@@ -22,7 +22,7 @@ EXPORTS = [
     "gpfq_prepare_columns_f32", "gpfq_quantization_f32", "gpfq_quantize_layer_f32", "gpfq_quantizer_f32",
     "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32", "gpfq_scratch_bytes",
     "gpfq_read_status", "gpfq_column_norms_f32", "gpfq_gather_patches_f32", "gpfq_last_launch_used_exchange",
-    "gpfq_describe_plan_mode", "gpfq_prepare_ws_bytes", "gpfq_prepare_columns_ws_f32",
+    "gpfq_describe_plan_mode", "gpfq_prepare_ws_bytes", "gpfq_prepare_columns_ws_f32", "gpfq_philox_uniform_f32",
 ]
 
 
@@ -74,6 +74,8 @@ def _load():
     lib.gpfq_column_norms_f32.argtypes = [vp, i64, i64, i64, vp, vp]
     lib.gpfq_gather_patches_f32.restype = i32
     lib.gpfq_gather_patches_f32.argtypes = [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64, vp]
+    lib.gpfq_philox_uniform_f32.restype = i32
+    lib.gpfq_philox_uniform_f32.argtypes = [u64, u64, u64, i64, vp, vp]
     lib.gpfq_scratch_bytes.restype = sz
     lib.gpfq_read_status.restype = i32
     lib.gpfq_read_status.argtypes = [vp, c.POINTER(c.c_int), vp]

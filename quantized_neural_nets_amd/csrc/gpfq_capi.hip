@@ -951,6 +951,17 @@ int gpfq_quantizer_f32(int mode, float step, const float* x, int64_t n, int K, f
     return GPFQ_OK;
 }
 
+int gpfq_philox_uniform_f32(uint64_t seed, uint64_t row_id0, uint64_t column, int64_t n, float* out, void* stream)
+{
+    if (!out || n < 0) return fail(GPFQ_ERR_ARG, "bad argument");
+    if (n == 0) return GPFQ_OK;
+    hipLaunchKernelGGL(gpfq::gpfq_philox_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       seed, row_id0, column, n, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "philox launch");
+    return GPFQ_OK;
+}
+
 int gpfq_column_norms_f32(const float* XT, int64_t D, int64_t m, int64_t m_pad, float* nrm2, void* stream)
 {
     if (!XT || !nrm2) return fail(GPFQ_ERR_ARG, "null pointer");

@@ -349,6 +349,15 @@ __global__ void gpfq_quantizer_kernel(int mode, float step, const float* __restr
     if (idx) idx[i] = id;
 }
 
+// The uniform draws of the stochastic quantizer as the LOOP kernels take them: out[i] = philox_uniform(seed, row_id0 + i,
+// column) -- one draw per row of the layer at one column.  For the standalone StepAlgorithm._stochastic_msq, so that the
+// name means one generator: quantizing the projections of column t with these draws is what the loop does at step t.
+__global__ void gpfq_philox_uniform_kernel(uint64_t seed, uint64_t row_id0, uint64_t column, int64_t n, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = philox_uniform(seed, row_id0 + (uint64_t)i, column);
+}
+
 // rowmax[i] = max_j |W[i][j]|  (max is exact, any order)
 __global__ void __launch_bounds__(256) gpfq_row_absmax_kernel(const float* __restrict__ W, int64_t ldw, int64_t d,
                                                               float* __restrict__ rowmax)

@@ -110,12 +110,20 @@ class StepAlgorithm:
     # arguments of _quantize_layer_ex / _quantization (plan=, seed=, event_hook=), and results are returned, never
     # parked on the class.
 
-    def _stochastic_msq(step_size, x, boundary_idx, lamb):
+    def _stochastic_msq(step_size, x, boundary_idx, lamb, seed=None, column=0, row_id0=0):
         '''Stochastic rounding to the alphabet, clipped to boundary_idx (step_algorithm.py:7-35).
-        Like the reference it overwrites and returns x.  The Bernoulli draws come from torch's CUDA
-        generator (torch.rand), not from the reference's CPU stream: distribution parity only.'''
-        un = torch.rand(x.shape, device=x.device, dtype=torch.float32)
-        x.copy_(_elementwise(_lib.MODE_STOCHASTIC, step_size, x, boundary_idx, lamb, un))
+        Like the reference it overwrites and returns x.  The draws come from the SAME counter-based generator the loop
+        kernels use -- element i takes U(seed, row row_id0 + i, column) -- so that this name means one stream: with the
+        layer's seed and column = t it is exactly the loop's quantizer at step t (tests/test_gpu_parity.py).  seed None:
+        the next value of the process-wide counter.  The reference draws from torch's CPU generator instead, which no GPU
+        path can reproduce: distribution parity only.'''
+        _lib.require_gpu_tensor(x, "x")
+        if seed is None:
+            seed = _default_seeds.take()
+        un = torch.empty((x.numel(),), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib.gpfq_philox_uniform_f32(int(seed), int(row_id0), int(column), un.numel(), _ptr(un),
+                                                    _lib.current_stream_ptr(x.device)))
+        x.copy_(_elementwise(_lib.MODE_STOCHASTIC, step_size, x, boundary_idx, lamb, un.view(x.shape)))
         return x
 
     def _msq(step_size, x, boundary_idx, lamb):

@@ -254,3 +254,34 @@ def test_cooperative_timeout_falls_back_to_whole_row_streaming(monkeypatch, orac
     SA._quantization(torch.from_numpy(W).to(dev), Q, U, torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev), SA._msq,
                      float(r["step"]), 8, 0.0)
     assert np.array_equal(U.cpu().numpy(), o["U"]) and np.array_equal(Q.cpu().numpy(), o["Q"])
+
+
+def test_cooperative_launches_on_two_streams_are_serialised():
+    """A cooperative grid is sized to be co-resident on an otherwise idle chip, so two of them must not run at once: the
+    scratch area is one per device, and a launch on another stream than the previous user's first waits (on the device)
+    for that stream.  Two chip-filling cooperative layers issued back to back on two streams, WITHOUT the host-side
+    status read in between: both finish without a timeout, with the results of the serial runs."""
+    from quantized_neural_nets_amd import StepAlgorithm as SA, _lib
+    import bench_workload as bw
+    dev = torch.device("cuda:0")
+    N, d, m = 64, 96, 93184
+    assert _lib.describe_plan(N, d, m).startswith("coop RT=2 C=8") and "grid=256" in _lib.describe_plan(N, d, m)
+    layers = []
+    for seed in (11, 12):
+        W, A, X = bw.synthetic_layer(N, d, m, seed, first_layer=False)
+        layers.append((W.to(dev), A.to(dev), X.to(dev), bw.layer_step(W)))
+    ref = [SA._quantize_layer_ex(W, A, X, m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev, compute_errors=False, step_override=st)
+           for W, A, X, st in layers]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    out = []
+    for (W, A, X, st), s in zip(layers, streams):
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            out.append(SA._quantize_layer_ex(W, A, X, m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev, compute_errors=False,
+                                             step_override=st, check_status=False))
+    for s in streams:
+        s.synchronize()
+    _lib.check_status(dev)                           # raises if either launch gave up waiting for a peer workgroup
+    for r, q in zip(ref, out):
+        assert torch.equal(r["idx"], q["idx"]) and torch.equal(r["U"], q["U"])

@@ -307,6 +307,15 @@ def test_stochastic_loop_matches_oracle_bitwise(qnn, oracle_mod):
     assert np.array_equal(r["U"].cpu().numpy(), U)
     assert not np.array_equal(idx, fx["idx"])           # it really is stochastic
     assert np.abs(idx).max() <= 8
+    # ONE generator behind the name: the standalone quantizer with the layer's seed and column = t is the loop's quantizer
+    # at step t.  Column 0: u = w_0 * a_0, s = <u, x_0> / ||x_0||^2 in the canonical order (the oracle's cdot).
+    x0, a0 = X[:, 0].astype(np.float32), A[:, 0].astype(np.float32)
+    r0 = np.sqrt(oracle_mod.cdot(x0, x0), dtype=np.float32)
+    n2 = np.float32(r0 * r0)
+    s0 = np.array([np.float32(oracle_mod.cdot((np.float32(w) * a0).astype(np.float32), x0)) / n2 for w in W[:, 0]], dtype=np.float32)
+    q0 = SA._stochastic_msq(float(r["step"]), torch.from_numpy(s0).to(DEV), 8, 0.0, seed=77, column=0, row_id0=0)
+    assert np.array_equal(q0.cpu().numpy().view(np.uint32), r["Q"][:, 0].cpu().numpy().view(np.uint32))
+    assert not torch.equal(q0, SA._stochastic_msq(float(r["step"]), torch.from_numpy(s0).to(DEV), 8, 0.0, seed=78))
 
 
 def test_cpu_tensors_are_refused(qnn):

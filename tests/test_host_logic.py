@@ -256,6 +256,13 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     real = json.load(open(newest))
     assert real["source_sha256"] == digest, "%s was collected on other kernel sources: re-collect (tools/profile_bench.sh)" % newest
     assert any("gpfq_resident_rt2_m0_w8" in k for k in real["kernels"]) and any("gpfq_coop_rt4_m0_w12" in k for k in real["kernels"])
+    # ... and so does the counter summary behind roofline_issue / the measured roofline_l2
+    newest_c = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters.json")),
+                      key=lambda f: [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(f))])[-1]
+    cnt = json.load(open(newest_c))
+    assert cnt["source_sha256"] == digest, "%s was collected on other kernel sources: re-collect (tools/profile_counters.sh)" % newest_c
+    dom = [v for k, v in cnt["kernels"].items() if "gpfq_resident_rt2_m0_w8" in k][0]["per_launch"]
+    assert 0.0 < dom["SQ_ACTIVE_INST_ANY"] / dom["SQ_WAVE_CYCLES"] <= 1.0 and dom["TCP_TCC_READ_REQ_sum"] > 0
     # the kernel names bench.py derives from a plan description are the names rocprofv3 reports
     assert bench.kernel_name("resident RT=2 waves=7 S=7 grid=(256,1) d=4608") == "gpfq_resident_rt2_m0_w8"
     assert bench.kernel_name("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == "gpfq_coop_rt4_m0_w12"
