@@ -44,7 +44,10 @@ def main():
             N, m = int(rng.integers(20, 200)), int(rng.integers(30000, 400000))
             rt = int(rng.choice([1, 2, 4]))
             os.environ["GPFQ_COOP_RT"] = str(rt)
-            os.environ["GPFQ_COOP_C"] = str(int(rng.choice([c for c in (8, 16, 32, 64, 128, 256) if rt * c <= (256 if rt == 1 else 128)])))
+            # (every member count a variant gathers: up to 256 for one and two rows, 64 and 256 -- not 128 -- for four)
+            os.environ["GPFQ_COOP_C"] = str(int(rng.choice([c for c in (8, 16, 32, 64, 128, 256) if rt < 4 or c != 128])))
+            if int(os.environ["GPFQ_COOP_C"]) >= 128:   # rows long enough for that many members (one segment each at least)
+                m = int(rng.integers(270000, 700000))
         elif fam == "chip_wide":                    # 256 granules, four gathered per lane: four rows x 64 members (columns
             if rng.integers(0, 2):                  # staged through LDS), or one row on 256 members; AUTO picks both
                 N, m = int(rng.integers(5, 40)), int(rng.integers(786433, 830000))
