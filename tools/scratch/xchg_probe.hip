@@ -19,10 +19,14 @@
 //         6: store as 0, poll = buffer_inv sc1 + plain load
 //         7: store as 0, poll = buffer_inv sc0 + plain load
 //         8: plain store, poll = buffer_inv sc0 + plain load
+//         9: PLAIN store (the line stays in the XCD's L2), poll with the sc1 load (bypasses the vector L1, L2-served): what
+//            members that share an XCD could use (round 3)
+//        10: sc0 store, sc1 load
 template <int VARIANT>
 __device__ __forceinline__ void publish(unsigned long long* p, unsigned long long v)
 {
-    if (VARIANT == 8) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory"); return; }
+    if (VARIANT == 8 || VARIANT == 9) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory"); return; }
+    if (VARIANT == 10) { asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory"); return; }
     if (VARIANT == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (VARIANT == 2) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -31,6 +35,7 @@ template <int VARIANT>
 __device__ __forceinline__ unsigned long long peek(unsigned long long* p)
 {
     if (VARIANT == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (VARIANT >= 9) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (VARIANT >= 4) {
         unsigned long long r;
         if (VARIANT == 4) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
@@ -109,6 +114,18 @@ int main()
     CK(hipMalloc(&xb, 256 * 2 * sizeof(unsigned long long) * 2)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&sink, 256 * 4));
     CK(hipMemset(bad, 0, 4));
     const int steps = 4000;
+    if (getenv("XCHG_ROUND3")) {        // round 3: plain / sc0 stores with sc1 loads, members on one XCD (and spread, for the record)
+        for (int work = 0; work <= 2; work += 2) {
+            printf("sweep stand-in %d x s_sleep 16\n%-8s %-10s %9s %12s %12s\n", work, "members", "placement", "sc1/sc1", "plain/sc1", "sc0/sc1");
+            for (int C = 2; C <= 32; C <<= 1)
+                for (int one = 1; one >= 0; --one) {
+                    printf("%-8d %-10s %9.3f %12.3f %12.3f\n", C, one ? "one XCD" : "spread", run<0>(xb, bad, sink, C, steps, one, work, 0),
+                           run<9>(xb, bad, sink, C, steps, one, work, 0), run<10>(xb, bad, sink, C, steps, one, work, 0));
+                    fflush(stdout);
+                }
+        }
+        return 0;
+    }
     for (int work = 0; work <= 2; work += 2) {
         const float base0 = run<0>(xb, bad, sink, 1, steps, 0, work, 0);
         printf("pause standing in for the sweep: %d x s_sleep 16; a step without partners (C = 1): %.3f us   (-1: stale for ever)\n", work, base0);
