@@ -989,10 +989,17 @@ int gpfq_gather_patches_f32(const float* x, int64_t B, int64_t C, int64_t H, int
     if (Lh < 1 || Lw < 1) return fail(GPFQ_ERR_ARG, "kernel larger than the padded input");
     const int64_t D = C * kh * kw;
     if (D > 0x7fffffff || C * H * W > 0x7fffffffffffLL) return fail(GPFQ_ERR_UNSUPPORTED, "feature map too large");
-    dim3 grid((unsigned)(m_pad / 64), (unsigned)((D + 63) / 64), 1);
+    const int64_t nrows = C * kh;                                       // feature rows (c, i): kw contiguous values each
+    dim3 grid((unsigned)(m_pad / 64), (unsigned)((nrows + 15) / 16), 1);
     if (grid.y > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "too many features");
-    hipLaunchKernelGGL(gpfq::gpfq_gather_patches_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (int)C, (int)H, (int)W,
-                       kh, kw, pad_h, pad_w, dil_h, dil_w, (int)Lw, Lh * Lw, patch_index, m, outT, m_pad, (int)D);
+#define GPFQ_LAUNCH_GATHER(KWV)                                                                                       \
+    hipLaunchKernelGGL(gpfq::gpfq_gather_patches_kernel<KWV>, grid, dim3(256), 0, (hipStream_t)stream, x, (int)C, (int)H, (int)W, \
+                       kh, kw, pad_h, pad_w, dil_h, dil_w, (int)Lw, Lh * Lw, patch_index, m, outT, m_pad, (int)D)
+    if (kw == 3) GPFQ_LAUNCH_GATHER(3);
+    else if (kw == 5) GPFQ_LAUNCH_GATHER(5);
+    else if (kw == 7) GPFQ_LAUNCH_GATHER(7);
+    else GPFQ_LAUNCH_GATHER(0);
+#undef GPFQ_LAUNCH_GATHER
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "gather_patches launch");
     (void)B;

@@ -300,14 +300,21 @@ __global__ void __launch_bounds__(64) gpfq_colnorm_finish_kernel(const float* __
 // straight into the transposed, zero-padded column layout the loop kernels read (row f = feature (c, i, j),
 // channel-major; column k = sampled patch k).  Patches sit on a grid whose stride is the KERNEL SIZE, as the
 // reference's nn.Unfold(kernel_size, dilation, padding, kernel_size) does (quantize_neural_net.py:320).
-// Replaces unfold + transpose + reshape + index (quantize_neural_net.py:334-347) and gpfq_transpose_pad_kernel.
-// blockDim = 256: 64 patches x 4 feature lanes; grid = (m_pad / 64, ceil(D / 64)).
+// Replaces unfold + transpose + reshape + index (quantize_neural_net.py:334-347) and the transposing pass.
+// A thread owns one patch (lane = patch: the stores of one feature are 256 contiguous bytes per wave) and walks feature
+// ROWS r = (c, i): the kw values (c, i, 0 .. kw-1) of a patch are contiguous in the image, so with KW == 3 / 5 / 7 and the
+// row inside the image they are ONE 12-byte load (16 + 4, 16 + 12) instead of kw 4-byte ones -- the capture is bound by its scattered reads
+// (a sampled patch uses kw * 4 bytes of every line it touches), not by its stores.  KW == 0: any kernel width, element by
+// element.  blockDim = 256: 64 patches x 4 row lanes; grid = (m_pad / 64, ceil(C * kh / 16)): 16 feature rows per workgroup.
+template <int KW>
 __global__ void __launch_bounds__(256) gpfq_gather_patches_kernel(const float* __restrict__ x, int C, int H, int W,
                                                                   int kh, int kw, int ph, int pw, int dh, int dw,
                                                                   int Lw, int64_t L, const int64_t* __restrict__ patch,
                                                                   int64_t m, float* __restrict__ outT, int64_t m_pad, int D)
 {
-    const int kx = threadIdx.x & 63, fy = threadIdx.x >> 6;
+    typedef float f3 __attribute__((ext_vector_type(3), aligned(4)));
+    typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+    const int kx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int64_t k = (int64_t)blockIdx.x * 64 + kx;
     const bool live = k < m;
     int64_t b = 0;
@@ -320,14 +327,52 @@ __global__ void __launch_bounds__(256) gpfq_gather_patches_kernel(const float* _
         x0 = (l % Lw) * kw - pw;
     }
     const float* __restrict__ img = x + b * (int64_t)C * H * W;
-    const int tile_y = (int)gridDim.y - 1 - (int)blockIdx.y;           // last feature tile first (see gpfq_transpose_pad_kernel)
-    const int f_end = min(D, (tile_y + 1) * 64);
-    for (int f = tile_y * 64 + fy; f < f_end; f += 4) {
-        const int c = f / (kh * kw), r = f - c * (kh * kw);
-        const int yy = y0 + (r / kw) * dh, xx = x0 + (r % kw) * dw;
-        float v = 0.0f;
-        if (live && yy >= 0 && yy < H && xx >= 0 && xx < W) v = img[((int64_t)c * H + yy) * W + xx];
-        outT[(int64_t)f * m_pad + k] = v;
+    const int kwr = KW ? KW : kw;
+    const int nrows = C * kh;
+    const int tile_r = (int)gridDim.y - 1 - (int)blockIdx.y;           // last feature rows first (see gpfq_transpose_pad_kernel)
+    const int r_end = min(nrows, (tile_r + 1) * 16);
+    const bool row_inside = dw == 1 && x0 >= 0 && x0 + kwr <= W;       // the whole row of the patch lies in the image
+    for (int r = tile_r * 16 + ry; r < r_end; r += 4) {
+        const int c = r / kh, i = r - c * kh;
+        const int yy = y0 + i * dh;
+        const bool rowok = live && yy >= 0 && yy < H;
+        const float* __restrict__ src = img + ((int64_t)c * H + yy) * W + x0;
+        float* __restrict__ dst = outT + (int64_t)r * kwr * m_pad + k;
+        if constexpr (KW == 3 || KW == 5 || KW == 7) {
+            float v[KW];
+#pragma unroll
+            for (int j = 0; j < KW; ++j) v[j] = 0.0f;
+            if (rowok) {
+                if (row_inside) {                   // one or two loads for the whole row (4-byte aligned vector loads)
+                    if constexpr (KW == 3) {
+                        const f3 t = *reinterpret_cast<const f3*>(src);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z;
+                    } else {
+                        const f4 t = *reinterpret_cast<const f4*>(src);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                        if constexpr (KW == 5) {
+                            v[4] = src[4];
+                        } else {
+                            const f3 u = *reinterpret_cast<const f3*>(src + 4);
+                            v[4] = u.x; v[5] = u.y; v[6] = u.z;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KW; ++j)
+                        if (x0 + j * dw >= 0 && x0 + j * dw < W) v[j] = src[j * dw];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KW; ++j) dst[(int64_t)j * m_pad] = v[j];
+        } else {
+            for (int j = 0; j < kwr; ++j) {
+                const int xx = x0 + j * dw;
+                float v = 0.0f;
+                if (rowok && xx >= 0 && xx < W) v = src[j * dw];
+                dst[(int64_t)j * m_pad] = v;
+            }
+        }
     }
 }
 

@@ -104,3 +104,19 @@ def test_bench_launches_its_own_ranks():
     # and a child that fails makes the parent fail (no silent rc 0)
     bad = subprocess.run(cmd + ["--plan", "9"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert bad.returncode != 0
+
+
+def test_bench_emulated_world_is_rank_zero_of_the_sharded_run():
+    """`bench.py --emulate-world 8` (the per-rank step of an 8-GPU run, measured on one GPU: rank 0's rows of every layer,
+    full columns, no collective) quantizes exactly the rows `dist.partition` gives rank 0 -- its output and oracle checks
+    run on those rows -- and marks its line as a projection."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--layers", "layer3.0", "--no-cpu-baseline",
+           "--emulate-world", "8"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["emulated_world"] == 8 and "projection" in rec
+    assert rec["output_check"]["mismatches"] == 0 and rec["output_check"]["weights"] == 32 * 2304       # 256 rows / 8
+    assert rec["oracle_shape_check"]["mismatches"] == 0 and rec["oracle_shape_check"]["shapes"] == 1
+    assert "coop RT=1 C=8" in out.stderr                   # the plan of a 32-row shard of layer3.0.conv2, not of the full layer

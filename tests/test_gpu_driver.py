@@ -76,6 +76,9 @@ def test_ignore_layers_and_unsupported_layer_type():
     (2, 8, 9, 9, 1, 0, 1, 1),
     (3, 5, 16, 16, 3, 2, 2, 0.3),
     (2, 70, 8, 8, 5, 2, 1, 0.25),        # more than 64 features per patch column block
+    (3, 6, 12, 12, 3, 1, 1, 0.5),        # 3 x 3, padding 1: patch rows inside the image (one 12-byte load) and across its edge
+    (2, 4, 23, 23, 5, 2, 1, 0.5),        # 5 x 5: 16 + 4 bytes per row
+    (2, 3, 30, 30, 7, 3, 1, 1),          # 7 x 7 stem: 16 + 12 bytes per row, every patch kept
 ])
 def test_fused_capture_equals_unfold_path(cfg):
     """gpfq_gather_patches_f32 (patches straight into the column layout) == unfold -> transpose -> reshape -> index
