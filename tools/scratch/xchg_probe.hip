@@ -22,10 +22,45 @@
 //         9: PLAIN store (the line stays in the XCD's L2), poll with the sc1 load (bypasses the vector L1, L2-served): what
 //            members that share an XCD could use (round 3)
 //        10: sc0 store, sc1 load
+//        11: PLAIN vector store, poll through the SCALAR path (s_load_dwordx16 glc: the scalar cache's port to L2, not the
+//            vector-memory queue the column requests stand in) -- members on one XCD only
+//        12: scalar store too (s_store_dwordx2 glc + s_dcache_wb)
+typedef unsigned v16u __attribute__((ext_vector_type(16)));
+template <int OFF>
+__device__ __forceinline__ v16u sload16(const void* p)
+{
+    v16u r;
+    asm volatile("s_load_dwordx16 %0, %1, %2 glc" : "=s"(r) : "s"(p), "n"(OFF) : "memory");
+    return r;
+}
+// all C (<= 32) granules of a tile: epochs complete?  sum of the values in v
+template <int C>
+__device__ __forceinline__ bool scalar_poll(const unsigned long long* xb_, unsigned epoch, float& v)
+{
+    v16u r0 = sload16<0>(xb_), r1 = r0, r2 = r0, r3 = r0;
+    if (C > 8) r1 = sload16<64>(xb_);
+    if (C > 16) { r2 = sload16<128>(xb_); r3 = sload16<192>(xb_); }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3) :: "memory");
+    bool ok = true;
+    v = 0.0f;
+#pragma unroll
+    for (int g = 0; g < C; ++g) {
+        const v16u& r = g < 8 ? r0 : g < 16 ? r1 : g < 24 ? r2 : r3;
+        ok = ok && r[2 * (g & 7) + 1] == epoch;
+        v += __uint_as_float(r[2 * (g & 7)]);
+    }
+    return ok;
+}
 template <int VARIANT>
 __device__ __forceinline__ void publish(unsigned long long* p, unsigned long long v)
 {
-    if (VARIANT == 8 || VARIANT == 9) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory"); return; }
+    if (VARIANT == 12) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        const unsigned long long sv = ((unsigned long long)hi << 32) | lo;
+        asm volatile("s_store_dwordx2 %0, %1, 0x0 glc\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" :: "s"(sv), "s"(p) : "memory");
+        return;
+    }
+    if (VARIANT == 8 || VARIANT == 9 || VARIANT == 11) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory"); return; }
     if (VARIANT == 10) { asm volatile("global_store_dwordx2 %0, %1, off sc0" :: "v"(p), "v"(v) : "memory"); return; }
     if (VARIANT == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (VARIANT == 2) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -64,10 +99,28 @@ __global__ void __launch_bounds__(64) xchg(unsigned long long* xb, int C, int st
         const unsigned epoch = (unsigned)t + 1u;
         unsigned long long* xb_ = base + (size_t)(t & 1) * C;
         for (int i = 0; i < work; ++i) __builtin_amdgcn_s_sleep(16);
-        if (lane == 0) publish<VARIANT>(xb_ + c, ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
+        if (VARIANT == 12) publish<VARIANT>(xb_ + c, ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
+        else if (lane == 0) publish<VARIANT>(xb_ + c, ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
         for (int i = 0; i < first_pause; ++i) __builtin_amdgcn_s_sleep(4);
         unsigned spins = dead ? (1u << 13) : 0u;
         float v = 0.0f;
+        if (VARIANT >= 11) {
+            for (;;) {
+                bool ok;
+                switch (C) {
+                case 2: ok = scalar_poll<2>(xb_, epoch, v); break;
+                case 4: ok = scalar_poll<4>(xb_, epoch, v); break;
+                case 8: ok = scalar_poll<8>(xb_, epoch, v); break;
+                case 16: ok = scalar_poll<16>(xb_, epoch, v); break;
+                default: ok = scalar_poll<32>(xb_, epoch, v); break;
+                }
+                if (ok) break;
+                if (++spins > (1u << 13)) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            acc += v;
+            continue;
+        }
         for (;;) {
             unsigned long long ok = ~0ull;
             v = 0.0f;
@@ -114,6 +167,19 @@ int main()
     CK(hipMalloc(&xb, 256 * 2 * sizeof(unsigned long long) * 2)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&sink, 256 * 4));
     CK(hipMemset(bad, 0, 4));
     const int steps = 4000;
+    if (getenv("XCHG_SCALAR")) {        // round 3: polls (and stores) through the scalar path, members on one XCD
+        for (int work = 0; work <= 2; work += 2) {
+            printf("sweep stand-in %d x s_sleep 16\n%-8s %9s %12s %14s %14s\n", work, "members", "sc1/sc1", "plain/sc1", "plain/s_load", "s_store/s_load");
+            for (int C = 2; C <= 32; C <<= 1) {
+                printf("%-8d %9.3f %12.3f %14.3f", C, run<0>(xb, bad, sink, C, steps, 1, work, 0), run<9>(xb, bad, sink, C, steps, 1, work, 0),
+                       run<11>(xb, bad, sink, C, steps, 1, work, 0));
+                fflush(stdout);
+                printf(" %14.3f\n", getenv("XCHG_SSTORE") ? run<12>(xb, bad, sink, C, steps, 1, work, 0) : 0.0f);
+                fflush(stdout);
+            }
+        }
+        return 0;
+    }
     if (getenv("XCHG_ROUND3")) {        // round 3: plain / sc0 stores with sc1 loads, members on one XCD (and spread, for the record)
         for (int work = 0; work <= 2; work += 2) {
             printf("sweep stand-in %d x s_sleep 16\n%-8s %-10s %9s %12s %12s\n", work, "members", "placement", "sc1/sc1", "plain/sc1", "sc0/sc1");
