@@ -16,17 +16,23 @@ for a in sys.argv[1:]:
     dl = min(d, 512)
     W, A, X = bw.synthetic_layer(N, d, m, 99, d_limit=dl)
     step = bw.layer_step(W)
+    loop_ms = []
+    def hook(tag, shape):                        # events around the loop kernel: cycles / time = the clock it ran at
+        if tag in ("loop_begin", "loop_end"):
+            e = torch.cuda.Event(enable_timing=True); e.record(); loop_ms.append(e)
     for it in range(2):
+        del loop_ms[:]
         StepAlgorithm._quantize_layer_ex(W.to(dev), A.to(dev), X.to(dev), m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev,
-                                         compute_errors=False, step_override=step)
+                                         compute_errors=False, step_override=step, event_hook=hook)
     torch.cuda.synchronize()
+    ms = loop_ms[0].elapsed_time(loop_ms[1])
     scr = _lib.scratch(dev)
     dbg = scr[96 * 1024 + 64: 96 * 1024 + 64 + 128].view(torch.int64).cpu().tolist()
     desc = _lib.describe_plan(N, dl, m)
-    print(a, desc)
+    print(a, desc, "loop %.3f ms = %.3f us/step" % (ms, ms * 1e3 / dl))
     if desc.startswith("resident"):
         names = ["loop bookkeeping, last quarter of the loads, history", "wait for column t (vmcnt)", "sweeps", "first quarter of the loads, lane trees, LDS write, second quarter",
                  "barrier", "third quarter, LDS read, slot tree, divisions, quantizer, readlanes", "-", "-"]
     for w, off in (("wave0", 0), ("lastwave", 8)):
         tot = sum(dbg[off:off + 8])
-        print("  %-8s total %.0f cyc/step:" % (w, tot / dl), "  ".join("%s %.0f" % (names[i], dbg[off + i] / dl) for i in range(8)))
+        print("  %-8s total %.0f cyc/step (clock %.2f GHz):" % (w, tot / dl, tot / dl / (ms * 1e3 / dl) / 1e3), "  ".join("%s %.0f" % (names[i], dbg[off + i] / dl) for i in range(8)))
