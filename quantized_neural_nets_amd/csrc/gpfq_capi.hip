@@ -402,6 +402,25 @@ int launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool ve
     return GPFQ_OK;
 }
 
+// Pause before the first poll of an exchange, in units of 256 clocks.  A poll that comes back incomplete costs a round trip
+// AND stands in the way of the granules still travelling: every member polls every line of the tile's block, members^2 / 16
+// line requests per round on the one memory channel that block lives on -- so the first poll waits about as long as the
+// slowest member's store needs, and that grows with the MEMBERS.  Measured optimum (tools/scratch/poll_delay_sweep.py; per
+// column against the round-2 rule, 2 wherever 32 granules were awaited): 64 members 8 (4.72 -> 4.18 us), 128: 16
+// (9.29 -> 8.16), 256: 16-24 (9.21 -> 8.65), 32: 4, 16 members with two or four rows 3-4 (in rounds 51.1 -> 47.8); beyond
+// the optimum every unit costs its 0.1 us.  Small tiles reach the exchange close together and a pause only costs (one row
+// x 16 members: 0 -> 4 is 1.46 -> 1.78 us; 2 x 8, 2 x 4, 4 x 4: 0) -- except four rows x 8 (2: 2.86 -> 2.76) and the
+// LDS-staged 13-wave kernel, whose members arrive further apart (four rows x 4 members in rounds: 3, 25.0 -> 22.7).
+int first_poll_pause(int RT, int C, bool lds)
+{
+    if (C >= 128) return 16;
+    if (C >= 64) return 8;
+    if (C >= 32) return 4;
+    if (C >= 16) return RT >= 2 ? 4 : 0;
+    if (C == 4 && lds) return 3;
+    return RT * C >= 32 ? 2 : 0;
+}
+
 gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, bool vec, void* scratch)
 {
     gpfq::SlabParams sp;
@@ -418,9 +437,8 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     const bool fast_ok = p.qc.step >= 0x1p-40f && p.qc.step <= 0x1p40f && p.qc.Kf <= 1024.0f && !env_int("GPFQ_EXACT_DIVISIONS", 0);
     sp.inv_step = fast_ok ? 1.0f / p.qc.step : __builtin_nanf("");
     sp.msq_thr = 0.5f - (p.qc.Kf + 4.0f) * 0x1p-18f;
-    // bit 0: pause before the first poll of an exchange (reducer_section: where 32 or more granules are awaited)
-    sp.spin_limit = 2u * (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit) +
-                    (env_int("GPFQ_COOP_POLL_DELAY", pl.RT * pl.C >= 32 ? 1 : 0) ? 1u : 0u);
+    // (low byte: pause before the first poll of an exchange, in units of 256 clocks -- launch_coop, which knows the kernel)
+    sp.spin_limit = 256u * (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit);
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
@@ -538,6 +556,7 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     // must land within a step) 3.47 vs 3.29 and 21.9 vs 20.6, and 197 segments in rounds (1.6 MB of columns per step
     // and XCD) 139 vs 102 -- members together.
     gpfq::SlabParams spx = sp;
+    spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_COOP_POLL_DELAY", first_poll_pause(RT, pl.C, lds)) & 31u);
     const bool depth1 = (RT == 4 && maxw == 12) || (RT == 2 && maxw == 16);
     spx.xcd_tiles = env_int("GPFQ_COOP_XCD_TILES", (!depth1 && pl.S <= 128) ? 1 : 0);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);

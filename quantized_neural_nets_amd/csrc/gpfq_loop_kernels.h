@@ -97,7 +97,7 @@ struct SlabParams {
     float step, Kf, lamb;
     float inv_step;    // fl(1 / step) for quant_msq_from_dot; NaN switches the division-free path off
     float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
-    unsigned spin_limit;    // cooperative kernels: 2 * (polls before an exchange gives up) + (pause before the first poll ? 1 : 0)
+    unsigned spin_limit;    // cooperative kernels: 256 * (polls before an exchange gives up) + (pause before the first poll, in units of 256 clocks: 0 .. 31)
     uint64_t seed, row_id0;
 };
 
@@ -167,15 +167,26 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         // lanes that gather nothing count as arrived; the compare mask goes straight into the scalar unit
         const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
         // Pacing.  A poll that comes back without every granule costs a whole round trip AND sits in the way of the granules
-        // still travelling: where 32 or more granules are awaited (the host sets the flag) the first poll waits 8 pauses
-        // (512 clocks), about the time the slowest member's store needs.  Measured per column: 197-segment rows, 4 rows x
-        // 32 members, 93 -> 72 us; 181 segments, 4 x 16, 6.1 -> 5.7; 91 segments, 4 x 8, 2.84 -> 2.77; with 16 granules or
-        // fewer the pause costs (1 x 16: 1.52 -> 1.79, 2 x 8: 1.31 -> 1.47, 4 x 4: + 2-6 % over a layer); the gap between
-        // two polls makes no difference that survives a whole-workload run.
-        // (The flag rides in bit 0 of the spin limit, which this loop keeps in a scalar register anyway: a flag of its own,
-        // or a test on C, is one more live scalar, and the four-row kernels then restore spilt SGPRs on this very path:
-        // + 2.6 % on layer3.0.conv2.)
-        if (p.spin_limit & 1u) __builtin_amdgcn_s_sleep(8);
+        // still travelling, so the first poll waits -- the host says how long (low byte of the spin limit, units of 256
+        // clocks; gpfq_capi.hip first_poll_pause: it grows with the members of the tile, 0 for small tiles, where a pause
+        // only costs: 1 x 16 granules 1.52 -> 1.79 us per column, 2 x 8 1.31 -> 1.47, 4 x 4 + 2-6 % over a layer).  The gap
+        // between two polls makes no difference that survives a whole-workload run.
+        // (The pause rides in the spin limit, which this loop keeps in a scalar register anyway: a value of its own, or a
+        // test on C, is one more live scalar, and the four-row kernels then restore spilt SGPRs on this very path: + 2.6 %
+        // on layer3.0.conv2.)
+        // (ONE opaque statement: a C++ loop here is two more basic blocks in the middle of the step, and the register
+        // allocator answers them with SGPR spills that are restored on this very path)
+        {
+            unsigned w = p.spin_limit & 31u;
+            asm volatile("s_cmp_eq_u32 %0, 0\n\t"
+                         "s_cbranch_scc1 2f\n"
+                         "1:\n\t"
+                         "s_sleep 4\n\t"
+                         "s_sub_u32 %0, %0, 1\n\t"
+                         "s_cmp_lg_u32 %0, 0\n\t"
+                         "s_cbranch_scc1 1b\n"
+                         "2:" : "+s"(w) :: "scc", "memory");
+        }
         if constexpr (QUAD) {
             // (eight members per lane: two batches of four loads, each summed as soon as it has been checked -- sixteen
             // registers of granules in flight do not fit beside two residual rows and the column window)
@@ -199,7 +210,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                 else if constexpr (G == 8) v4 = vq[0] + vq[1];
                 else v4 = (vq[0] + vq[1]) + (vq[2] + vq[3]);
                 if ((ok | idle) == __builtin_amdgcn_read_exec()) break;
-                if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
+                if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             v = want ? v4 : 0.0f;
@@ -207,7 +218,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) | idle) == __builtin_amdgcn_read_exec()) break;
-                if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
+                if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             v = want ? __uint_as_float((unsigned)gv) : 0.0f;
@@ -218,7 +229,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                 gw = __hip_atomic_load(src1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) &
                       __builtin_amdgcn_ballot_w64((unsigned)(gw >> 32) == epoch)) | idle) == __builtin_amdgcn_read_exec()) break;
-                if ((spins += 2) > p.spin_limit) { timed_out = true; break; }
+                if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             v = want ? __uint_as_float((unsigned)gv) + __uint_as_float((unsigned)gw) : 0.0f;

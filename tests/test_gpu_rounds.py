@@ -164,6 +164,30 @@ def test_rounds_stop_after_a_timeout_and_the_layer_is_redone(monkeypatch):
     assert torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"])
 
 
+def test_first_poll_pause_changes_no_bit(monkeypatch):
+    """The pause before the first poll of an exchange (gpfq_capi.hip first_poll_pause, by members; GPFQ_COOP_POLL_DELAY
+    overrides it, units of 256 clocks, 0 .. 31) is timing only: none, the table's and the longest give the same bits --
+    on the register-window kernel and on the LDS-staged one."""
+    from quantized_neural_nets_amd import StepAlgorithm as SA, _lib
+    for (N, d, m, want) in ((24, 6, 60000, "coop RT="), (300, 5, 51200, "coop RT=4 C=4 waves=13")):
+        assert _lib.describe_plan(N, d, m).startswith(want), _lib.describe_plan(N, d, m)
+        W, A, X = bw.synthetic_layer(N, d, m, 77 + N, first_layer=False)
+        step = bw.layer_step(W)
+        outs = []
+        for delay in (None, "0", "31"):
+            if delay is None:
+                monkeypatch.delenv("GPFQ_COOP_POLL_DELAY", raising=False)
+            else:
+                monkeypatch.setenv("GPFQ_COOP_POLL_DELAY", delay)
+            r = SA._quantize_layer_ex(W.to(DEV), A.to(DEV), X.to(DEV), m, 1.16 / 8, 8, 1, None, 0.05, 1, False,
+                                      torch.device(DEV), step_override=step, plan=0, compute_errors=False)
+            torch.cuda.synchronize()
+            assert not r["timeouts"]
+            outs.append(r)
+        for r in outs[1:]:
+            assert torch.equal(r["idx"], outs[0]["idx"]) and torch.equal(r["Q"], outs[0]["Q"]) and torch.equal(r["U"], outs[0]["U"])
+
+
 @pytest.mark.parametrize("mode", ["msq", "soft", "stochastic"])
 def test_depthwise_long_rows_one_row_per_group(oracle_mod, mode):
     """Depthwise convolutions (groups == out channels, one row per group, every group with its own 9 columns) with long
