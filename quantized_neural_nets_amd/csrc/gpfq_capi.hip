@@ -409,16 +409,18 @@ int launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool ve
 // column against the round-2 rule, 2 wherever 32 granules were awaited): 64 members 8 (4.72 -> 4.18 us), 128: 16
 // (9.29 -> 8.16), 256: 16-24 (9.21 -> 8.65), 32: 4, 16 members with two or four rows 3-4 (in rounds 51.1 -> 47.8); beyond
 // the optimum every unit costs its 0.1 us.  Small tiles reach the exchange close together and a pause only costs (one row
-// x 16 members: 0 -> 4 is 1.46 -> 1.78 us; 2 x 8, 2 x 4, 4 x 4: 0) -- except four rows x 8 (2: 2.86 -> 2.76) and the
+// x 16 members: 0 -> 4 is 1.46 -> 1.78 us; 2 x 8, 2 x 4, 4 x 4: 0) -- except four rows x 8 on 12 waves and the
 // LDS-staged 13-wave kernel, whose members arrive further apart (four rows x 4 members in rounds: 3, 25.0 -> 22.7).
-int first_poll_pause(int RT, int C, bool lds)
+int first_poll_pause(int RT, int C, int waves, bool lds)
 {
     if (C >= 128) return 16;
     if (C >= 64) return 8;
     if (C >= 32) return 4;
     if (C >= 16) return RT >= 2 ? 4 : 0;
     if (C == 4 && lds) return 3;
-    return RT * C >= 32 ? 2 : 0;
+    // (four rows x 8 members: 2 with 12 sweep waves, 2.86 -> 2.76 us per column; none with 7 -- EfficientNet-B1's 50-segment
+    // rows 1.14 -> 1.02 ms per layer: the fewer waves, the closer together the members arrive)
+    return RT * C >= 32 && waves > 8 ? 2 : 0;
 }
 
 gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, bool vec, void* scratch)
@@ -556,7 +558,7 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     // must land within a step) 3.47 vs 3.29 and 21.9 vs 20.6, and 197 segments in rounds (1.6 MB of columns per step
     // and XCD) 139 vs 102 -- members together.
     gpfq::SlabParams spx = sp;
-    spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_COOP_POLL_DELAY", first_poll_pause(RT, pl.C, lds)) & 31u);
+    spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_COOP_POLL_DELAY", first_poll_pause(RT, pl.C, pl.waves, lds)) & 31u);
     const bool depth1 = (RT == 4 && maxw == 12) || (RT == 2 && maxw == 16);
     spx.xcd_tiles = env_int("GPFQ_COOP_XCD_TILES", (!depth1 && pl.S <= 128) ? 1 : 0);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The plain bench lines of a build (no profiler attached), on the GPU box:   gpurun -- 'bash tools/bench_lines.sh r03_v4'
+# The plain bench lines of a build (no profiler attached), on the GPU box:   gpurun -- 'bash tools/bench_lines.sh r03_v5'
 # headline (+ per-layer table), the secondary workloads, the capture path, the emulated per-rank steps of 2 / 4 / 8 GPUs.
 # bench.py quotes PMC summaries only from profiles/ and only with the digest of the sources it runs: with
 # profiles/<tag>_pmc_{traffic,counters}.json of THIS build in place the headline line carries roofline.traffic,
