@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#define XB_BYTES (64u << 20)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
 // VARIANT 0: relaxed agent-scope atomic store / load (global_store_dwordx2 sc1, global_load_dwordx2 sc1) -- the product
@@ -82,25 +83,29 @@ __device__ __forceinline__ unsigned long long peek(unsigned long long* p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ int g_lstride = 16;       // granules between the starts of two consecutive 128-byte lines of a block (16 = contiguous)
 template <int VARIANT>
 __global__ void __launch_bounds__(64) xchg(unsigned long long* xb, int C, int steps, int one_xcd, int work, int first_pause,
                                            unsigned* bad, float* sink)
 {
+    const int lstride = g_lstride;
+#define GOFF(g) (((g) >> 4) * lstride + ((g) & 15))
     const int wg = blockIdx.x, lane = threadIdx.x;
     const int tiles = gridDim.x / C;
     int tile, c;
     if (!one_xcd) { tile = wg / C; c = wg % C; }            // consecutive workgroup ids = round robin over the 8 XCDs
     else { const int xcd = wg & 7, slot = wg >> 3; tile = xcd * (tiles >> 3) + slot / C; c = slot % C; }
-    unsigned long long* base = xb + (size_t)tile * 2 * C;
+    const int blk = ((C + 15) >> 4) * lstride;                 // granules a (tile, parity) block spans
+    unsigned long long* base = xb + (size_t)tile * 2 * blk;
     const int per = (C + 63) >> 6;                           // granules per lane
     float acc = 0.0f;
     bool dead = false;
     for (int t = 0; t < steps; ++t) {
         const unsigned epoch = (unsigned)t + 1u;
-        unsigned long long* xb_ = base + (size_t)(t & 1) * C;
+        unsigned long long* xb_ = base + (size_t)(t & 1) * blk;
         for (int i = 0; i < work; ++i) __builtin_amdgcn_s_sleep(16);
-        if (VARIANT == 12) publish<VARIANT>(xb_ + c, ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
-        else if (lane == 0) publish<VARIANT>(xb_ + c, ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
+        if (VARIANT == 12) publish<VARIANT>(xb_ + GOFF(c), ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
+        else if (lane == 0) publish<VARIANT>(xb_ + GOFF(c), ((unsigned long long)epoch << 32) | (unsigned)__float_as_uint(1.0f + c));
         for (int i = 0; i < first_pause; ++i) __builtin_amdgcn_s_sleep(4);
         unsigned spins = dead ? (1u << 13) : 0u;
         float v = 0.0f;
@@ -127,7 +132,7 @@ __global__ void __launch_bounds__(64) xchg(unsigned long long* xb, int C, int st
             for (int i = 0; i < per; ++i) {
                 const int g = i * 64 + lane;
                 const bool want = g < C;
-                const unsigned long long gv = peek<VARIANT>(xb_ + (want ? g : 0));
+                const unsigned long long gv = peek<VARIANT>(xb_ + (want ? GOFF(g) : 0));
                 ok &= __builtin_amdgcn_ballot_w64(!want || (unsigned)(gv >> 32) == epoch);
                 v += want ? __uint_as_float((unsigned)gv) : 0.0f;
             }
@@ -148,7 +153,7 @@ static float run(unsigned long long* xb, unsigned* bad, float* sink, int C, int 
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
-        CK(hipMemset(xb, 0, 256 * 2 * sizeof(unsigned long long) * 2));
+        CK(hipMemset(xb, 0, XB_BYTES));
         CK(hipEventRecord(a));
         xchg<VARIANT><<<256, 64>>>(xb, C, steps, one_xcd, work, pause, bad, sink);
         CK(hipEventRecord(b));
@@ -164,9 +169,26 @@ static float run(unsigned long long* xb, unsigned* bad, float* sink, int C, int 
 int main()
 {
     unsigned long long* xb; unsigned* bad; float* sink;
-    CK(hipMalloc(&xb, 256 * 2 * sizeof(unsigned long long) * 2)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&sink, 256 * 4));
+    CK(hipMalloc(&xb, XB_BYTES)); CK(hipMalloc(&bad, 4)); CK(hipMalloc(&sink, 256 * 4));
     CK(hipMemset(bad, 0, 4));
     const int steps = 4000;
+    if (getenv("XCHG_STRIDE")) {       // round 3: the lines of a tile's granule block spread over memory (bytes between line starts)
+        const int strides[] = {128, 256, 512, 1024, 4096, 65536};
+        printf("sc1 store / sc1 load, members spread over the XCDs, sweep stand-in 2 x s_sleep 16, first poll after 3 x s_sleep 4\n%-8s", "members");
+        for (int sb : strides) printf(" %8d", sb);
+        printf("\n");
+        for (int C = 16; C <= 256; C <<= 1) {
+            printf("%-8d", C);
+            for (int sb : strides) {
+                int ls = sb / 8;
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lstride), &ls, sizeof(int)));
+                printf(" %8.3f", run<0>(xb, bad, sink, C, steps, 0, 2, 3));
+                fflush(stdout);
+            }
+            printf("\n");
+        }
+        return 0;
+    }
     if (getenv("XCHG_SCALAR")) {        // round 3: polls (and stores) through the scalar path, members on one XCD
         for (int work = 0; work <= 2; work += 2) {
             printf("sweep stand-in %d x s_sleep 16\n%-8s %9s %12s %14s %14s\n", work, "members", "sc1/sc1", "plain/sc1", "plain/s_load", "s_store/s_load");
