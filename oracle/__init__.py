@@ -5,6 +5,6 @@ The product package (quantized_neural_nets_amd) never does.
 """
 from .gpfq_oracle import (  # noqa: F401
     MODE_MSQ, MODE_SOFT, MODE_HARD, MODE_STOCHASTIC,
-    build, quantizer_vec, quantization, quantize_layer, cdot, alphabet_step, max_threads,
+    build, quantizer_vec, quantization, quantize_layer, cdot, alphabet_step, max_threads, philox_uniform_vec,
     torch_restatement_quantization,
 )

@@ -106,6 +106,12 @@ float gpfq_oracle_philox_uniform(uint64_t seed, uint64_t row, uint64_t col)
     return (float)(c0 >> 8) * (1.0f / 16777216.0f);
 }
 
+/* the draws of rows row0 .. row0 + n - 1 at one column (what the loop's stochastic quantizer consumes at that step) */
+void gpfq_oracle_philox_uniform_vec(uint64_t seed, uint64_t row0, uint64_t col, long n, float* out)
+{
+    for (long i = 0; i < n; ++i) out[i] = gpfq_oracle_philox_uniform(seed, row0 + (uint64_t)i, col);
+}
+
 /* step_algorithm.py:27-35  p = 1 - x/step + floor(x/step); Bernoulli(p) -> round down, else up; clip */
 float gpfq_oracle_stochastic(float step, float x, int K, float uniform, int* idx)
 {

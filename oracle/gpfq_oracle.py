@@ -51,6 +51,8 @@ def _load():
         lib.gpfq_oracle_cdot.argtypes = [_f32p, _f32p, ctypes.c_long]
         lib.gpfq_oracle_philox_uniform.restype = ctypes.c_float
         lib.gpfq_oracle_philox_uniform.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
+        lib.gpfq_oracle_philox_uniform_vec.restype = None
+        lib.gpfq_oracle_philox_uniform_vec.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_long, _f32p]
         lib.gpfq_oracle_max_threads.restype = ctypes.c_int
         _lib = lib
     return _lib
@@ -82,6 +84,14 @@ def quantizer_vec(mode, step, x, K, lamb=0.0, uniform=None):
                                       _p(un) if un is not None else None, _p(out),
                                       idx.ctypes.data_as(_i32p))
     return out, idx
+
+
+def philox_uniform_vec(seed, row0, col, n):
+    """The stochastic quantizer's draws U[0,1) for rows row0 .. row0+n-1 at one column (Philox4x32-10 keyed by
+    (seed, row, column): the counter-based stand-in for torch.bernoulli's global stream, step_algorithm.py:28)."""
+    out = np.empty((int(n),), np.float32)
+    _load().gpfq_oracle_philox_uniform_vec(int(seed), int(row0), int(col), int(n), _p(out))
+    return out
 
 
 def cdot(u, x):

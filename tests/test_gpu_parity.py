@@ -67,6 +67,39 @@ def test_stochastic_quantizer_is_unbiased(qnn):
     assert q.cpu().tolist() == [1.0, -1.0]
 
 
+def test_stochastic_quantizer_against_reference_fixture(qnn, oracle_mod):
+    """G7 (tools/make_golden.py gen_stochastic, from the reference's _stochastic_msq, step_algorithm.py:7-35):
+    (i) where the answer does not depend on the draw the HIP quantizer returns the reference's bits; (ii) inside the
+    alphabet its two possible answers are bitwise the reference's two, its draws are bitwise the oracle's Philox stream
+    (so its round-down count IS the oracle's), and that count agrees with the reference's own frequency within a
+    binomial bound (6 sigma of the difference of two samples)."""
+    from quantized_neural_nets_amd import StepAlgorithm as SA
+    from quantized_neural_nets_amd.step_algorithm import _elementwise
+    from quantized_neural_nets_amd import _lib
+    from test_oracle_golden import g7_expected_down_probability, g7_binomial_slack
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g7_stochastic.npz"))
+    top = np.float32(1) - np.float32(2 ** -24)
+    for ci, c in enumerate(json.loads(str(fx["meta"]))["configs"]):
+        x, ref = fx["det_x_%d" % ci], fx["det_q_%d" % ci]
+        for seed in (0, 123456789):
+            out = SA._stochastic_msq(c["step"], _t(x.copy()), c["K"], 0.0, seed=seed, column=ci).cpu().numpy()
+            assert np.array_equal(out.view(np.uint32), ref.view(np.uint32)), (ci, seed)
+        x, lo, hi, ref_down = (fx["rnd_%s_%d" % (k, ci)] for k in ("x", "lo", "hi", "down_count"))
+        n = c["draws"]
+        for u, want in ((0.0, lo), (top, hi)):
+            out = _elementwise(_lib.MODE_STOCHASTIC, c["step"], _t(x), c["K"], 0.0, _t(np.full(x.shape, u, np.float32))).cpu().numpy()
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (ci, u)
+        p = g7_expected_down_probability(x, c["step"]).astype(np.float64)
+        for j in range(0, len(x), 3):
+            xs = torch.full((n,), float(x[j]), device=DEV, dtype=torch.float32)
+            q = SA._stochastic_msq(c["step"], xs, c["K"], 0.0, seed=77 + ci, column=j, row_id0=0).cpu().numpy()
+            un = oracle_mod.philox_uniform_vec(seed=77 + ci, row0=0, col=j, n=n)
+            qo, _ = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, c["step"], np.full(n, x[j], np.float32), c["K"], 0.0, uniform=un)
+            assert np.array_equal(q.view(np.uint32), qo.view(np.uint32)), (ci, j)          # same stream, same bits
+            down = int((q == lo[j]).sum())
+            assert abs(down - int(ref_down[j])) <= np.sqrt(2.0) * g7_binomial_slack(n, p[j]), (ci, j, down, int(ref_down[j]))
+
+
 @pytest.mark.parametrize("name", gi.available_cases())
 @pytest.mark.parametrize("plan", [0, 1, 3])
 def test_layer_against_reference_and_oracle(qnn, oracle_mod, name, plan):

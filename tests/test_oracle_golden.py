@@ -17,6 +17,7 @@ def test_fixtures_present():
     assert len(LOOP_CASES) == len(gi.CASES), "missing golden fixtures; run tools/make_golden.py in the build container"
     assert os.path.exists(os.path.join(gi.GOLDEN_DIR, "g1_quantizers.npz"))
     assert os.path.exists(os.path.join(gi.GOLDEN_DIR, "g5_driver.npz"))
+    assert os.path.exists(os.path.join(gi.GOLDEN_DIR, "g7_stochastic.npz"))
 
 
 def test_quantizer_known_answers(oracle_mod):
@@ -182,3 +183,51 @@ def test_tie_audit_rejects_a_real_mismatch_and_accepts_a_tie():
     assert rep["ties"] and rep["ties"][0]["margin"] == 0.0 and not rep["unexplained"]
     assert tie_audit.boundary_margin(0.5, 1.0, 8, 0.5, "L0", 0, 1) == 0.0
     assert tie_audit.boundary_margin(-2.0, 1.0, 8, 0.5, "L0", -2, -3) == pytest.approx(0.0)   # (|s|-lamb)/step = 1.5
+
+
+# ---- G7: the stochastic quantizer (step_algorithm.py:7-35) against what the reference itself returned ----------------
+def g7_expected_down_probability(x, step):
+    """p of step_algorithm.py:27 in the reference's own fp32 operations: (1 - x/step) + floor(x/step)."""
+    z = (np.asarray(x, np.float32) / np.float32(step)).astype(np.float32)
+    return ((np.float32(1) - z).astype(np.float32) + np.floor(z)).astype(np.float32)
+
+
+def g7_binomial_slack(n, p, sigmas=6.0):
+    return sigmas * np.sqrt(n * p * (1.0 - p)) + 2.0
+
+
+def test_stochastic_draw_independent_points_bitwise(oracle_mod):
+    """On the grid (p = 1), beyond the alphabet (both neighbours clip) and at +-0 the reference's answer does not depend
+    on torch.bernoulli's stream: the oracle returns the same bits whatever its own draw is."""
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g7_stochastic.npz"))
+    for ci, c in enumerate(json.loads(str(fx["meta"]))["configs"]):
+        x, ref = fx["det_x_%d" % ci], fx["det_q_%d" % ci]
+        for u in (0.0, 0.37, np.float32(1) - np.float32(2 ** -24)):
+            q, idx = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, c["step"], x, c["K"], 0.0,
+                                              uniform=np.full(x.shape, u, np.float32))
+            assert np.array_equal(q.view(np.uint32), ref.view(np.uint32)), (ci, u)
+            assert np.abs(idx).max() <= c["K"]
+
+
+def test_stochastic_values_and_frequencies_against_reference(oracle_mod):
+    """Inside the alphabet: the oracle's two possible answers are bitwise the two values the reference ever returned, and
+    over as many draws of its own generator it rounds down as often as the reference did (both binomial in the same p)."""
+    fx = np.load(os.path.join(gi.GOLDEN_DIR, "g7_stochastic.npz"))
+    for ci, c in enumerate(json.loads(str(fx["meta"]))["configs"]):
+        x, lo, hi, ref_down = (fx["rnd_%s_%d" % (k, ci)] for k in ("x", "lo", "hi", "down_count"))
+        n = c["draws"]
+        q0, _ = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, c["step"], x, c["K"], 0.0, uniform=np.zeros_like(x))
+        q1, _ = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, c["step"], x, c["K"], 0.0,
+                                         uniform=np.full(x.shape, np.float32(1) - np.float32(2 ** -24), np.float32))
+        assert np.array_equal(q0.view(np.uint32), lo.view(np.uint32)), ci       # draw below p: round down
+        assert np.array_equal(q1.view(np.uint32), hi.view(np.uint32)), ci       # draw at the top of [0, 1): round up
+        p = g7_expected_down_probability(x, c["step"]).astype(np.float64)
+        assert np.all(np.abs(ref_down - n * p) <= g7_binomial_slack(n, p)), "fixture itself off its own p"
+        for j, xv in enumerate(x):
+            un = oracle_mod.philox_uniform_vec(seed=77 + ci, row0=0, col=j, n=n)
+            q, _ = oracle_mod.quantizer_vec(oracle_mod.MODE_STOCHASTIC, c["step"], np.full(n, xv, np.float32), c["K"], 0.0,
+                                            uniform=un)
+            assert set(np.unique(q.view(np.uint32))) <= {lo[j:j + 1].view(np.uint32)[0], hi[j:j + 1].view(np.uint32)[0]}
+            down = int((q == lo[j]).sum())
+            assert abs(down - n * p[j]) <= g7_binomial_slack(n, p[j]), (ci, j, down, n * p[j])
+            assert abs(down - int(ref_down[j])) <= np.sqrt(2.0) * g7_binomial_slack(n, p[j]), (ci, j, down, int(ref_down[j]))

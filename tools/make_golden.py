@@ -4,7 +4,7 @@
 Container-only: /root/reference does not exist on the GPU box and nothing at test/bench time runs this.
 The fixtures hold data only (expected outputs + the digest of the regenerable inputs); no reference source.
 
-  python tools/make_golden.py            # all loop cases (G1-G4) + driver case (G5)
+  python tools/make_golden.py            # all loop cases (G1-G4) + driver case (G5) + G6 + G7
   python tools/make_golden.py --bench    # also time the true reference loop on the ResNet-50 3x3 shapes
 
 What is called (reference paths relative to /root/reference/src):
@@ -13,6 +13,7 @@ What is called (reference paths relative to /root/reference/src):
   StepAlgorithm._quantization (per group, for the residual U)       step_algorithm.py:107-148
   QuantizeNeuralNet(...).quantize_network()                         quantize_neural_net.py:32-214 -> g5_driver.npz
   StepAlgorithm._quantize_layer at headline scale, NO seed search   step_algorithm.py:151-249  -> g6_*.npz (idx + U digests)
+  StepAlgorithm._stochastic_msq (draw-independent points + frequencies) step_algorithm.py:7-35  -> g7_stochastic.npz
 """
 import argparse
 import io
@@ -75,6 +76,54 @@ def gen_quantizers(SA):
     out["meta"] = np.array(json.dumps(dict(configs=cfgs, provenance=provenance())))
     np.savez_compressed(os.path.join(gi.GOLDEN_DIR, "g1_quantizers.npz"), **out)
     print("g1_quantizers: %d configs" % len(cfgs))
+
+
+# ------------------------------------------------------------------------------------------------ G7
+def gen_stochastic(SA):
+    """The reference's _stochastic_msq (step_algorithm.py:7-35) as far as a random quantizer can be pinned:
+    (i)  arguments whose answer does not depend on the draw -- on the alphabet grid (p = 1: bernoulli(1) always rounds
+         down, to the argument itself), beyond the alphabet (|x| >= step*K: both neighbours clip to +-step*K), +-0 --
+         outputs kept bitwise;
+    (ii) for 64 arguments inside the alphabet, BOTH values the reference ever returns (bitwise: step*floor(x/step) and
+         step*(floor(x/step)+1)) and how often it returned the lower one over n seeded draws (torch.bernoulli on
+         torch's global CPU generator: the stream itself cannot be reproduced anywhere else, its frequencies can)."""
+    out, cfgs = {}, []
+    n = 1 << 17
+    for ci, (step, K) in enumerate([(0.25, 2), (0.0371, 8), (0.113, 1), (0.5, 128)]):
+        rng = np.random.default_rng(4242 + ci)
+        stf = np.float32(step)
+        st = torch.tensor(step, dtype=torch.float32)
+        # (i) draw-independent arguments
+        grid = (np.arange(-K - 3, K + 4, dtype=np.float32) * stf).astype(np.float32)        # z integer: p == 1
+        grid = grid[(grid / stf) == np.floor(grid / stf)]                                   # (keep those whose fp32 quotient IS an integer)
+        beyond = np.concatenate([(np.float32(K) + rng.uniform(0.01, 6.0, 40).astype(np.float32)) * stf,
+                                 -(np.float32(K) + rng.uniform(0.01, 6.0, 40).astype(np.float32)) * stf,
+                                 np.array([5.0, -5.0, 1000.0, -1000.0], np.float32) * max(1.0, float(K) * step)]).astype(np.float32)
+        det = np.concatenate([grid, beyond, np.array([0.0, -0.0], np.float32)]).astype(np.float32)
+        torch.manual_seed(1000 + ci)
+        r1 = SA._stochastic_msq(st, torch.from_numpy(det.copy()), K, 0.0).numpy().copy()
+        torch.manual_seed(2000 + ci)
+        r2 = SA._stochastic_msq(st, torch.from_numpy(det.copy()), K, 0.0).numpy().copy()
+        assert np.array_equal(r1.view(np.uint32), r2.view(np.uint32)), "a 'deterministic' argument depends on the draw"
+        out["det_x_%d" % ci], out["det_q_%d" % ci] = det, r1
+        # (ii) 64 arguments strictly inside the alphabet, off the grid
+        z = rng.uniform(-K, K, 64).astype(np.float32)
+        z[:8] = np.floor(z[:8]) + np.array([0.001, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9, 0.999], np.float32)
+        x = (z * stf).astype(np.float32)
+        zz = x / stf
+        x = x[(zz != np.floor(zz)) & (np.floor(zz) >= -K) & (np.floor(zz) + 1 <= K)]
+        torch.manual_seed(3000 + ci)
+        big = torch.from_numpy(np.repeat(x[:, None], n, axis=1).copy())          # (len(x), n): every argument n times
+        q = SA._stochastic_msq(st, big.reshape(-1), K, 0.0).reshape(len(x), n).numpy()
+        lo, hi = q.min(axis=1), q.max(axis=1)
+        assert np.all((q == lo[:, None]) | (q == hi[:, None])) and np.all(lo < hi)
+        out["rnd_x_%d" % ci] = x
+        out["rnd_lo_%d" % ci], out["rnd_hi_%d" % ci] = lo.astype(np.float32), hi.astype(np.float32)
+        out["rnd_down_count_%d" % ci] = (q == lo[:, None]).sum(axis=1).astype(np.int64)
+        cfgs.append(dict(step=float(stf), K=K, draws=n, torch_seed=3000 + ci))
+    out["meta"] = np.array(json.dumps(dict(configs=cfgs, provenance=provenance())))
+    np.savez_compressed(os.path.join(gi.GOLDEN_DIR, "g7_stochastic.npz"), **out)
+    print("g7_stochastic: %d configs, %d draws per argument" % (len(cfgs), n))
 
 
 # ------------------------------------------------------------------------------------------ G2/G3/G4
@@ -316,6 +365,8 @@ def main():
     SA = import_reference_step_algorithm()
     if args.only is None:
         gen_quantizers(SA)
+    if args.only is None or args.only in "g7_stochastic":
+        gen_stochastic(SA)
     for name in gi.CASES:
         if args.only is None or args.only in name:
             gen_loop_case(SA, name)
