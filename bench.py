@@ -80,6 +80,13 @@ def parse_args():
     return ap.parse_args()
 
 
+def launch_command(gpus, port, argv):
+    """The torch.distributed.run command line bench.py starts itself under for --gpus N > 1 (one rank per GPU, rendezvous
+    on 127.0.0.1: the container's hostname may not resolve) -- exactly the form the driver uses."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def self_launch(args):
     """--gpus N > 1 outside torchrun: run the same command under torch.distributed.run in a child process (never an
     exec: this process may not touch the GPU first, and does not), relay its stdout, return its exit code."""
@@ -87,8 +94,7 @@ def self_launch(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = launch_command(args.gpus, port, sys.argv[1:])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     log("bench.py: --gpus %d without a torch.distributed environment: launching %s" % (args.gpus, " ".join(cmd[1:9]) + " ..."))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
@@ -106,6 +112,27 @@ def self_launch(args):
         rc = 1
         log("bench.py: the distributed child printed no JSON line")
     return rc
+
+
+def expected_per_rank(workload, world):
+    """What ONE GPU measured for the rows rank 0 of a `world`-GPU run would own (`bench.py --emulate-world N`: every layer,
+    full columns, no collective), from the newest committed line under profiles/ -- so that a real N-GPU run can be held
+    against the projection of DESIGN.md 8 on sight.  None when no such line is committed for this workload / world."""
+    import glob
+    tag = "" if workload == "r50_3x3" else "_" + workload
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*emulated_world%d%s_line.json" % (world, tag))), reverse=True)
+    for path in paths:
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("emulated_world") == world:
+            return {"source": os.path.relpath(path, ROOT), "per_rank_ms_per_step": rec.get("ms_per_step"),
+                    "value": rec.get("value"), "prep_ms_per_step": rec.get("prep_ms_per_step"),
+                    "loop_ms_per_step": rec.get("loop_ms_per_step"),
+                    "note": "one GPU's time for rank 0's rows, no collective: a real run adds the per-layer all_gather / "
+                            "all_reduce (collective_ms) and the max over ranks"}
+    return None
 
 
 def cpu_baseline(data, gpu_idx, budget_s=20.0):
@@ -159,6 +186,29 @@ def cpu_baseline(data, gpu_idx, budget_s=20.0):
     base = {"value": round(tot_w / tot_t / 1e6, 5), "unit": "M weights/s", "cores": nthreads, "kind": "port",
             "sample": "torch-op restatement of step_algorithm.py:140-148 on " + "; ".join(sample),
             "host_cores": ncores, "c_oracle_value": round(tot_w_c / tot_t_c / 1e6, 5)}
+    if ncores > nthreads:
+        # SURVEY 8(d) asks for the baseline on ALL host cores: the same restatement with one torch thread per core, on a
+        # shorter sample of the same layers (a quarter of the budget) -- reported NEXT to the figure above, which stays
+        # `value` because it is the faster of the two on this box (the reference's small per-step ops do not scale to
+        # hundreds of threads; both numbers are in the line, so nobody has to take that on trust)
+        torch.set_num_threads(ncores)
+        aw = at = 0.0
+        for name, Wd, Ad, Xd, step, m in picked:
+            N, d = Wd.shape
+            cap = min(d, 128)
+            W, A, X = Wd[:, :cap].cpu().contiguous(), Ad[:, :cap].cpu().contiguous(), Xd[:, :cap].cpu().contiguous()
+            Q, U, stept = torch.zeros_like(W), torch.zeros(N, m), torch.tensor(step)
+            cols, t0 = 0, time.perf_counter()
+            while cols < cap and (cols < 8 or time.perf_counter() - t0 < budget_s / 4 / len(picked)):
+                oracle.torch_restatement_quantization(W[:, cols:cols + 4], Q[:, cols:cols + 4], U, A[:, cols:cols + 4],
+                                                      X[:, cols:cols + 4], stept, 8)
+                cols += 4
+            aw += N * cols
+            at += time.perf_counter() - t0
+        torch.set_num_threads(nthreads)
+        base["all_cores"] = {"cores": ncores, "value": round(aw / at / 1e6, 5), "unit": "M weights/s",
+                             "sample": "the same restatement and layers, torch.set_num_threads(%d), first >= 8 columns each" % ncores}
+        log("cpu baseline with all %d cores: %.4f Mw/s (with %d threads: %.4f)" % (ncores, aw / at / 1e6, nthreads, tot_w / tot_t / 1e6))
     return base, {"against": "CPU oracle, first 128 columns of %d layers" % len(picked), "weights": checked,
                   "mismatches": mismatches}
 
@@ -448,6 +498,10 @@ def main():
             ev.record()
             events.append((cur["name"], tag, ev))
 
+    if qdist.active() is not None:
+        # events around the layer-end all_gather of the index shards (dist.quantize_sharded), on the launch stream
+        qdist.active().event_hook = lambda tag: hook(tag, None)
+
     def gather(fmap, geom, sel, m):
         """the driver's fused capture (quantize_neural_net.py SaveInputConv2d): sampled patches -> (D, m_pad) columns"""
         import ctypes
@@ -531,6 +585,7 @@ def main():
         one_step(keep=(s == args.steps - 1))
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     cur["on"] = False
     gc.enable()
     _lib.check_status(dev)
@@ -559,17 +614,26 @@ def main():
 
     # ---- per-launch durations of the loop kernel from the events recorded on the launch stream
     per_layer = {}
-    assert len(events) % 3 == 0
-    for i in range(0, len(events), 3):
-        (n0, tg0, e0), (n1, tg1, e1), (n2, tg2, e2) = events[i], events[i + 1], events[i + 2]
-        assert (tg0, tg1, tg2) == ("prepare_begin", "loop_begin", "loop_end") and n0 == n1 == n2
-        rec = per_layer.setdefault(n0, {"prep_ms": 0.0, "loop_ms": 0.0, "n": 0})
-        rec["prep_ms"] += e0.elapsed_time(e1)
-        rec["loop_ms"] += e1.elapsed_time(e2)
-        rec["n"] += 1
+    open_ev = {}
+    for name_, tag, ev in events:
+        rec = per_layer.setdefault(name_, {"prep_ms": 0.0, "loop_ms": 0.0, "coll_ms": 0.0, "n": 0})
+        if tag == "prepare_begin":
+            open_ev = {"prepare_begin": ev}
+        elif tag == "loop_begin":
+            rec["prep_ms"] += open_ev["prepare_begin"].elapsed_time(ev)
+            open_ev["loop_begin"] = ev
+        elif tag == "loop_end":
+            rec["loop_ms"] += open_ev["loop_begin"].elapsed_time(ev)
+            rec["n"] += 1
+        elif tag == "collective_begin":
+            open_ev["collective_begin"] = ev
+        elif tag == "collective_end":
+            rec["coll_ms"] += open_ev["collective_begin"].elapsed_time(ev)
+        else:
+            raise AssertionError("unknown event tag %r" % tag)
     fam = {}
     table = []
-    prep_ms_total = loop_ms_total = 0.0
+    prep_ms_total = loop_ms_total = coll_ms_total = 0.0
     for name, N, dg, m, groups in (l[:5] for l in layers):
         rec = per_layer.get(name)
         if not rec:
@@ -596,6 +660,7 @@ def main():
         lm, pm = rec["loop_ms"] / rec["n"], rec["prep_ms"] / rec["n"]
         prep_ms_total += pm
         loop_ms_total += lm
+        coll_ms_total += rec["coll_ms"] / rec["n"]
         row = ("%-22s N=%4d d=%5d g=%4d m=%6d %-26s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg = %5.1f%% of 8 TB/s HBM%s)  prep %7.3f ms"
                % (name, N, dg, groups, m, " ".join(desc.split()[:3]) + (" x%d" % plan_rounds(desc) if plan_rounds(desc) > 1 else ""), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
                   "" if l2b is None else "; %5.0f GB/s L2 columns = %4.1f%% of 34.5 TB/s" % (l2b / lm / 1e6, l2b / lm / 1e6 / L2_PEAK_GBPS * 100),
@@ -606,7 +671,21 @@ def main():
     if rank == 0 and args.layer_table:
         with open(args.layer_table, "w") as fh:
             fh.write("\n".join(table) + "\n")
+    # every rank's own split of a step (events on its launch stream), collected on rank 0
+    mine = {"rank": rank, "prep_ms": round(prep_ms_total, 3), "loop_ms": round(loop_ms_total, 3),
+            "collective_ms": round(coll_ms_total, 3), "wall_ms_per_step": round(elapsed_local / args.steps * 1e3, 3)}
+    per_rank = [mine]
+    if pg and world > 1:
+        per_rank = [None] * world
+        td.all_gather_object(per_rank, mine)
 
+    # The PMC passes behind the committed summaries run the HEADLINE workload with its full layers, the transposing
+    # preparation and every row on one GPU (tools/profile_bench.sh): the same kernel name launched on other shapes -- another
+    # workload, a subset of layers or columns, a shard's rows, the capture path's or the prefetching run's timing -- moves
+    # other bytes in other times, so no counter is quoted there.
+    headline_shapes = (args.workload == "r50_3x3" and args.layers is None and default_batch and world == 1 and not args.max_cols
+                       and not args.distinct_shapes and not args.capture and args.emulate_world <= 1 and not args.force_shard
+                       and not args.prefetch_analog)
     if rank == 0:
         dom = max(fam, key=lambda k: fam[k]["ms"]) if fam else None
         roofline = roofline_l2 = None
@@ -614,10 +693,7 @@ def main():
             f = fam[dom]
             achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
             digest = _lib.kernel_source_digest()
-            # the PMC passes behind the committed summary run the HEADLINE workload (tools/profile_bench.sh): the same kernel
-            # name launched on another workload's shapes moves other bytes, so nothing is quoted there
-            if args.workload == "r50_3x3" and args.layers is None and default_batch and world == 1 and not args.max_cols \
-                    and not args.distinct_shapes:
+            if headline_shapes:
                 traffic, tsrc = pmc_traffic(dom, digest)
             else:
                 traffic, tsrc = None, "PMC summaries are collected on the headline workload only (tools/profile_bench.sh)"
@@ -647,8 +723,7 @@ def main():
                                "whole_job_frac": round(sum(v["l2"] for v in fam.values() if v["l2_known"]) /
                                                        (sum(v["ms"] for v in fam.values() if v["l2_known"]) * 1e-3) / 1e9 / L2_PEAK_GBPS, 4)}
         roofline_issue = None
-        if dom and fam[dom]["l2_known"] and args.workload == "r50_3x3" and args.layers is None and default_batch and world == 1 \
-                and not args.max_cols and not args.distinct_shapes:
+        if dom and fam[dom]["l2_known"] and headline_shapes:
             cr, csrc = counter_rooflines(dom, fam[dom], _lib.kernel_source_digest(), roofline_l2)
             if cr:
                 roofline_issue = cr["issue"]
@@ -681,6 +756,9 @@ def main():
                                        "single GPU, sharded path forced (one-rank %s group)" % args.backend if args.force_shard else "single GPU")},
             "roofline_whole_job_frac": round(sum(alg_bytes.values()) * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS / max(world, 1), 4),
             "prep_ms_per_step": round(prep_ms_total, 3), "loop_ms_per_step": round(loop_ms_total, 3),
+            "collective_ms_per_step": round(coll_ms_total, 3),
+            "per_rank": per_rank,
+            **({"expected": expected_per_rank(args.workload, world)} if world > 1 else {}),
             "cooperative_timeouts": len(timeouts),
             "roofline": roofline,
             "roofline_l2": roofline_l2,

@@ -1,5 +1,5 @@
 """Makes `quantized_neural_nets_amd` importable when ONLY this directory is on sys.path (the reference's
-main.py is run from its own src/ directory with `PYTHONPATH=<repo>/compat`): the package lives one level up."""
+main.py is run from its own src/ directory through `python <repo>/compat/run_main.py`): the package lives one level up."""
 import os
 import sys
 

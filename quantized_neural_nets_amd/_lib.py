@@ -117,6 +117,26 @@ def current_stream_ptr(device):
 _scratch = {}           # device index -> scratch buffer
 _scratch_user = {}      # device index -> the stream whose launches used the scratch last
 _scratch_lock = threading.Lock()
+_exclusive = {}         # device index -> re-entrant lock held from scratch() through the launch and its status read
+
+
+def exclusive(device):
+    """The per-device lock a caller holds from `scratch()` through its launches AND the read of their status word.
+    The scratch area (exchange granules, status words) is one per device: two host threads on two streams that both
+    passed `scratch()` before either launched would run two cooperative grids on the same granules at once, and either
+    thread's status read would consume (and clear) a timeout raised by the other's launch.  Inside the lock the order is
+    total: the previous user's work is waited for on the device (`scratch()`), this thread's launches are queued, and
+    its status read -- a stream synchronisation -- ends before the next thread may even ask for the scratch.
+    (`check_status=False` callers release the lock with their launches only QUEUED: the device-side wait of the next
+    `scratch()` still keeps the grids apart, but whose timeout a deferred status read reports is then the caller's
+    business -- defer only from one thread.)"""
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _scratch_lock:
+        lk = _exclusive.get(index)
+        if lk is None:
+            lk = _exclusive[index] = threading.RLock()
+    return lk
 
 
 def scratch(device):
@@ -124,7 +144,8 @@ def scratch(device):
     once.  A cooperative grid is sized to be co-resident on an otherwise idle chip (a plain launch behind an occupancy
     query), so two of them running at once on two streams would each be only partly resident and spin to their
     bounds: launches that use the scratch are therefore serialised per device -- a caller on another stream than the
-    previous user's first waits (on the device, not the host) for everything that stream has queued."""
+    previous user's first waits (on the device, not the host) for everything that stream has queued.  Call it, launch
+    and read the status inside `with exclusive(device):` (host threads; see there)."""
     dev = torch.device(device)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(index)

@@ -80,6 +80,13 @@ int env_int(const char* name, int dflt)
 int slab_max_waves(bool coop, int RT);
 int resident_max_rt(int waves);
 
+// GPFQ_COOP_SPIN_LIMIT (polls before an exchange gives up), clamped to what the kernels' 32-bit word can carry scaled by 256
+int clamped_spin_limit()
+{
+    const int v = env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit);
+    return v < 0 ? 0 : (v > (1 << 24) - 1 ? (1 << 24) - 1 : v);
+}
+
 // Is there an instantiation of the cooperative kernel for (rows per workgroup, sweep waves, members) with this
 // quantizer?  Answered by the same table the launch uses (coop_kernel_for, below), so that a pair without one is never
 // CHOSEN: the plan that is described is the plan that launches.  (Today every pair exists for all four quantizers.)
@@ -372,7 +379,7 @@ int launch_stream(const Plan& pl, const gpfq::LoopParams& p, int groups, bool ve
     const size_t shm = sizeof(float) * (2 * RT * (size_t)n_max + 2 * (RT + 1));
     gpfq::StreamCoop sc;
     sc.C = C; sc.tiles = pl.tiles; sc.xbuf = nullptr; sc.status = nullptr;
-    sc.spin_limit = (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit);
+    sc.spin_limit = (unsigned)clamped_spin_limit();
     hipError_t e;
     if (C > 1) {
         const int nblocks = pl.tiles * C;
@@ -439,8 +446,10 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     const bool fast_ok = p.qc.step >= 0x1p-40f && p.qc.step <= 0x1p40f && p.qc.Kf <= 1024.0f && !env_int("GPFQ_EXACT_DIVISIONS", 0);
     sp.inv_step = fast_ok ? 1.0f / p.qc.step : __builtin_nanf("");
     sp.msq_thr = 0.5f - (p.qc.Kf + 4.0f) * 0x1p-18f;
-    // (low byte: pause before the first poll of an exchange, in units of 256 clocks -- launch_coop, which knows the kernel)
-    sp.spin_limit = 256u * (unsigned)env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit);
+    // (low FIVE bits: pause before the first poll of an exchange, in units of 256 clocks, 0 .. 31 -- launch_coop, which knows
+    // the kernel; the kernel reads `& 31u`.)  The poll count is clamped to [0, 2^24 - 1] before it is scaled: 256 * 2^24
+    // wraps a 32-bit word to 0 -- every exchange would give up at once -- and a negative value casts to a huge one.
+    sp.spin_limit = 256u * (unsigned)clamped_spin_limit();
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;

@@ -97,7 +97,7 @@ struct SlabParams {
     float step, Kf, lamb;
     float inv_step;    // fl(1 / step) for quant_msq_from_dot; NaN switches the division-free path off
     float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
-    unsigned spin_limit;    // cooperative kernels: 256 * (polls before an exchange gives up) + (pause before the first poll, in units of 256 clocks: 0 .. 31)
+    unsigned spin_limit;    // cooperative kernels: 256 * (polls before an exchange gives up, host-clamped to < 2^24) + (low five bits: pause before the first poll, in units of 256 clocks, 0 .. 31)
     uint64_t seed, row_id0;
 };
 
@@ -167,7 +167,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         // lanes that gather nothing count as arrived; the compare mask goes straight into the scalar unit
         const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
         // Pacing.  A poll that comes back without every granule costs a whole round trip AND sits in the way of the granules
-        // still travelling, so the first poll waits -- the host says how long (low byte of the spin limit, units of 256
+        // still travelling, so the first poll waits -- the host says how long (low five bits of the spin limit, units of 256
         // clocks; gpfq_capi.hip first_poll_pause: it grows with the members of the tile, 0 for small tiles, where a pause
         // only costs: 1 x 16 granules 1.52 -> 1.79 us per column, 2 x 8 1.31 -> 1.47, 4 x 4 + 2-6 % over a layer).  The gap
         // between two polls makes no difference that survives a whole-workload run.

@@ -25,6 +25,7 @@ class ShardContext:
         self.world = td.get_world_size(group)
         self.gather_residual = gather_residual
         self.force = force
+        self.event_hook = None      # optional callable(tag): "collective_begin" / "collective_end" around the index all_gather
 
 
 def enable(group=None, gather_residual=False, force=False):
@@ -87,6 +88,17 @@ def rebuild_q(idx, step, K, mode, lamb):
 
 def _all_gather_rows(ctx, local, chunk_rows):
     """all_gather of equally sized row blocks (local is padded to chunk_rows rows)."""
+    hook = getattr(ctx, "event_hook", None)
+    if hook:
+        hook("collective_begin")
+    try:
+        return _all_gather_rows_impl(ctx, local, chunk_rows)
+    finally:
+        if hook:
+            hook("collective_end")
+
+
+def _all_gather_rows_impl(ctx, local, chunk_rows):
     d = local.shape[1]
     if local.shape[0] < chunk_rows:
         pad = torch.zeros((chunk_rows - local.shape[0], d), dtype=local.dtype, device=local.device)

@@ -167,7 +167,6 @@ class StepAlgorithm:
         XT = torch.empty((max(d, 1), mp), device=dev, dtype=torch.float32)
         nrm2 = torch.empty((2 * max(d, 1),), device=dev, dtype=torch.float32)      # {norm, reciprocal} per column (ABI 3)
         st = _lib.current_stream_ptr(dev)
-        scr = _lib.scratch(dev)
         part = torch.empty((max(int(_lib.lib.gpfq_prepare_ws_bytes(d, m)), 4) // 4,), device=dev, dtype=torch.float32)
         _lib.check(_lib.lib.gpfq_prepare_columns_ws_f32(_ptr(A), lda, _ptr(X), ldx, m, d, _ptr(AT), _ptr(XT),
                                                         _ptr(nrm2), mp, _ptr(part), part.numel() * 4, st))
@@ -176,7 +175,7 @@ class StepAlgorithm:
         plan = _lib.PLAN_AUTO if plan is None else int(plan)
         U0 = None
 
-        def launch(pl):
+        def launch(pl, scr):
             _lib.check(_lib.lib.gpfq_quantization_f32(
                 _ptr(Wv), ldw, _ptr(Qv), ldq, _ptr(Uv), ldu, 1, _ptr(AT), _ptr(XT), _ptr(nrm2), N, d, m, mp,
                 float(step_size), int(boundary_idx), mode, float(lamb if lamb is not None else 0.0), int(seed), 0,
@@ -185,15 +184,27 @@ class StepAlgorithm:
 
         if plan != _lib.PLAN_STREAM_ROWS and N > 0 and d > 0:
             # this surface updates U in place, so a launch that gives up waiting for a peer workgroup has already
-            # spoilt its input: keep a copy whenever the launch MAY wait on other workgroups -- any plan but whole-row
-            # streaming (the plan that runs is decided inside the library: fallbacks, GPFQ_* overrides)
-            U0 = Uv.clone()
-        if launch(plan) and not _lib.status_ok(dev):
-            # never hand back what a timed-out launch left behind: redo on the plan that waits for nobody
-            if U0 is None:
-                raise _lib.GpfqError("a cooperative launch timed out and no copy of the initial residual was kept")
-            Uv.copy_(U0)
-            launch(_lib.PLAN_STREAM_ROWS)
+            # spoilt its input: keep a copy whenever the launch MAY wait on other workgroups.  An initial residual always
+            # streams (gpfq_capi.hip run_loop), and the library's own plan description -- the same choose_plan, the same
+            # GPFQ_* overrides -- says whether that streaming plan splits rows over workgroups ("C="); its only fallback
+            # is to whole rows, which waits for nobody.  Whole-row plans (depthwise layers: one call per group,
+            # step_algorithm.py:235-237) therefore pay no N x m copy per call.
+            asked = _lib.PLAN_STREAM if plan == _lib.PLAN_AUTO else plan
+            try:
+                may_wait = " C=" in _lib.describe_plan(N, d, m, 1, asked, mode)
+            except _lib.GpfqError:
+                may_wait = True
+            if may_wait:
+                U0 = Uv.clone()
+        # scratch -> launch -> status read under the device's lock: the scratch (granules, status words) is one per device
+        with _lib.exclusive(dev):
+            scr = _lib.scratch(dev)
+            if launch(plan, scr) and not _lib.status_ok(dev):
+                # never hand back what a timed-out launch left behind: redo on the plan that waits for nobody
+                if U0 is None:
+                    raise _lib.GpfqError("a cooperative launch timed out and no copy of the initial residual was kept")
+                Uv.copy_(U0)
+                launch(_lib.PLAN_STREAM_ROWS, scr)
         if Qv.data_ptr() != Q.data_ptr():
             Q.copy_(Qv)
         if Uv.data_ptr() != U.data_ptr():

@@ -55,6 +55,45 @@ def test_reference_import_lines_resolve_with_only_compat_on_path():
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
+def test_documented_command_binds_compat_ahead_of_same_named_src_modules(tmp_path):
+    """INTEGRATION.md A, as documented: `cd <reference>/src; python <repo>/compat/run_main.py ...`.  A stand-in src/ holds
+    modules with the reference's names (quantize_neural_net, step_algorithm, utils -- each would raise if imported), a
+    data_loaders.py with the reference's own import line (data_loaders.py:12) and a main.py made of the reference's import
+    lines (main.py:8-10): the shims must win for the three names, src/ must still provide data_loaders and main.py, and
+    the arguments must reach main.py untouched.  (`PYTHONPATH=compat python main.py` does NOT do this: the script's
+    directory precedes PYTHONPATH -- checked below as well, so that the documentation cannot drift back.)"""
+    src = tmp_path / "src"
+    src.mkdir()
+    for name in ("quantize_neural_net", "step_algorithm", "utils"):
+        (src / (name + ".py")).write_text("raise ImportError('the src/ module %s was imported, not the compat shim')\n" % name)
+    (src / "data_loaders.py").write_text("from utils import parse_imagenet_val_labels\n"
+                                         "def data_loader(*a, **k):\n    return 'src-data-loader'\n")
+    (src / "main.py").write_text(textwrap.dedent("""
+        import sys
+        from quantize_neural_net import QuantizeNeuralNet
+        from utils import test_accuracy, eval_sparsity, fusion_layers_inplace
+        from data_loaders import data_loader
+        import quantize_neural_net, utils, step_algorithm, data_loaders
+        import quantized_neural_nets_amd as pkg
+        assert QuantizeNeuralNet is pkg.QuantizeNeuralNet
+        assert __name__ == '__main__' and sys.argv[1:] == ['-model', 'alexnet', '-b', '4'], sys.argv
+        print('FILES', quantize_neural_net.__file__, utils.__file__, step_algorithm.__file__, data_loaders.__file__, __file__)
+    """))
+    env = dict(os.environ)
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, os.path.join(COMPAT, "run_main.py"), "-model", "alexnet", "-b", "4"],
+                       capture_output=True, text=True, env=env, cwd=str(src), timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    files = r.stdout.strip().splitlines()[-1].split()[1:]
+    assert all(f.startswith(COMPAT) for f in files[:3]), files
+    assert files[3].startswith(str(src)) and files[4].startswith(str(src)), files
+    # the tempting shorter command binds src/'s own modules (here: they raise) -- which is why the launcher exists
+    env["PYTHONPATH"] = COMPAT
+    r = subprocess.run([sys.executable, "main.py", "-model", "alexnet", "-b", "4"], capture_output=True, text=True, env=env,
+                       cwd=str(src), timeout=300)
+    assert r.returncode != 0 and "not the compat shim" in r.stderr
+
+
 def test_compat_modules_hold_no_logic():
     """every shim is imports and a docstring: no def, no class, no control flow"""
     import ast

@@ -4,6 +4,7 @@ rebuild used after the all_gather."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -357,3 +358,55 @@ def test_bench_counter_rooflines_are_bounded_and_digest_gated(tmp_path, monkeypa
     assert l2["measured"] and l2["request_bytes"] == 128 and l2["model"] == {"frac": 0.45}
     assert abs(l2["achieved"] - 226.5e6 * 128 / 2.244e-3 / 1e9) < 0.1 and abs(l2["frac"] - l2["achieved"] / 34500.0) < 1e-4
     assert abs(l2["l2_hit_rate"] - 219.7 / 227.0) < 1e-4 and l2["frac"] <= 1.0
+
+
+def test_bench_self_launch_builds_the_drivers_command_and_never_touches_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus N` (N > 1) outside torchrun starts itself under torch.distributed.run as a CHILD process --
+    the exact form the driver uses (one rank per GPU, rendezvous on 127.0.0.1), its own flags passed on untouched -- relays
+    the child's JSON line and exit code, and does so before anything initialises the GPU (an exec or a HIP call in the
+    parent would break the multi-process run on this pool)."""
+    import bench
+    import torch
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, **kw):
+            seen["cmd"], seen["kw"] = cmd, kw
+            seen["cuda_initialised_at_launch"] = torch.cuda.is_initialized()
+            self.stdout = iter(["rank 0 chatter\n", '{"metric": "m", "value": 1.0, "n_gpus": 4}\n'])
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2", "--workload", "r50_all"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    port = cmd[cmd.index("--master-port") + 1]
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                   "127.0.0.1", "--master-port", port, os.path.abspath(bench.__file__),
+                   "--gpus", "4", "--steps", "7", "--warmup", "2", "--workload", "r50_all"]
+    assert 1024 <= int(port) <= 65535
+    env = seen["kw"]["env"]
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["kw"].get("stdout") is not None and not seen["kw"].get("shell")
+    assert seen["cuda_initialised_at_launch"] is False and not torch.cuda.is_initialized()
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "m", "value": 1.0, "n_gpus": 4}' and "rank 0 chatter" in out.err
+    assert bench.launch_command(2, 29500, ["--gpus", "2"])[3:10] == ["--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                                                      "127.0.0.1", "--master-port", "29500"]
+
+
+def test_bench_expected_block_reads_the_committed_emulation_lines():
+    """`bench.py --gpus N` carries an `expected` block: the per-rank step ONE GPU measured for rank 0's rows of an N-GPU
+    world (bench.py --emulate-world N, committed under profiles/), so that SCALE can be held against DESIGN.md 8."""
+    import bench
+    for wl in ("r50_3x3", "r50_all"):
+        for n in (2, 4, 8):
+            e = bench.expected_per_rank(wl, n)
+            assert e is not None and e["source"].startswith("profiles/") and e["per_rank_ms_per_step"] > 0 and e["value"] > 0
+    assert bench.expected_per_rank("r50_3x3", 3) is None
