@@ -75,6 +75,10 @@ def parse_args():
     ap.add_argument("--prefetch-analog", action="store_true",
                     help="prepare the ANALOG columns of layer i+1 on a side stream while the loop of layer i runs (they do not "
                          "depend on the layers quantized before; the quantized columns stay serial, as in the real driver)")
+    ap.add_argument("--driver", default=None, choices=["r18", "r50"],
+                    help="time QuantizeNeuralNet.quantize_network() itself -- what the reference's main.py:120-125 times -- on a "
+                         "builder-owned ResNet-18 (batch 256) / ResNet-50 (batch 1024) with random weights and synthetic "
+                         "images, and print the split forward / capture / preparation / loop / metrics / write-back")
     ap.add_argument("--oracle-budget", type=float, default=2e9,
                     help="oracle_shape_check: rows x columns x m per shape the CPU oracle is given (0 = skip the check)")
     return ap.parse_args()
@@ -387,8 +391,97 @@ def counter_rooflines(dom, fam_rec, digest, l2_model):
     return {"issue": issue, "l2": l2}, src
 
 
+def driver_bench(args):
+    """`--driver r18|r50`: ONE call of QuantizeNeuralNet.quantize_network() on a real block architecture at the config's
+    calibration batch (BASELINE.json configs 1 and 3 on one GPU), wall-clocked the way the reference's main.py:120-125
+    clocks it, and split by stream events at the driver's phase boundaries (QuantizeNeuralNet.timing_hook):
+      forward     the two partial forwards per layer up to the hooked layer (quantize_neural_net.py:256-269)
+      capture     the hooks: patch sampling (np.random.choice per image) + the fused gather into the column layout (:325-350)
+      prepare     column preparation still missing behind the capture (norms; transposes for Linear layers)
+      loop        the GPFQ loop kernels (step_algorithm.py:140-148)
+      metrics     status read + error metrics (one A @ W.T GEMM, :216-219)
+      write_back  Q into the quantized network, the two printed errors (.cpu(): a sync), the index copy for packed.save
+      between     host work between layers: gc.collect (:211-212), the loader's next batch, prints
+    Random-init weights and random images (no checkpoints, no ImageNet here): the loop's cost does not depend on values."""
+    import contextlib
+    import numpy as np
+    import torch
+    from quantized_neural_nets_amd import QuantizeNeuralNet, arch
+    from quantized_neural_nets_amd.main import SyntheticLoader
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    dev = torch.device("cuda", 0)
+    name, named_batch = {"r18": ("resnet18", 256), "r50": ("resnet50", 1024)}[args.driver]
+    batch = args.batch or named_batch
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = arch.ARCHITECTURES[name]().to(dev).eval()
+    q = QuantizeNeuralNet(model, name, batch, SyntheticLoader(batch, 224, 1), mlp_bits=4, cnn_bits=4, ignore_layers=[],
+                          mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16, mlp_percentile=1, cnn_percentile=1, reg=None,
+                          lamb=0.1, retain_rate=0.25, stochastic_quantization=False, device=dev)
+    # one untimed forward of a full batch: the convolution library picks (and, on a fresh box, builds) its kernels here
+    # rather than inside the timed call
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        model(torch.randn(batch, 3, 224, 224, device=dev))
+    torch.cuda.synchronize()
+    log("driver bench: %s, batch %d; untimed warm-up forward %.1fs" % (name, batch, time.perf_counter() - t0))
+    events = []
+
+    def mark(tag, layer_idx):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        events.append((tag, layer_idx, ev))
+
+    q.timing_hook = mark
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(sys.stderr):         # the driver prints per layer, like the reference
+        q.quantize_network()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    phase_of = {("forward_begin", "capture_begin"): "forward", ("capture_begin", "capture_end"): "capture",
+                ("prepare_begin", "loop_begin"): "prepare", ("loop_begin", "loop_end"): "loop",
+                ("loop_end", "metrics_end"): "metrics", ("metrics_end", "layer_end"): "write_back",
+                ("layer_end", "layer_begin"): "between", ("layer_begin", "forward_begin"): "between",
+                ("capture_end", "forward_begin"): "between", ("capture_end", "prepare_begin"): "between"}
+    split = {k: 0.0 for k in ("forward", "capture", "prepare", "loop", "metrics", "write_back", "between")}
+    per_layer = {}
+    for (tg0, l0, e0), (tg1, l1, e1) in zip(events[:-1], events[1:]):
+        ph = phase_of.get((tg0, tg1))
+        if ph is None:
+            raise AssertionError("unexpected phase boundary %s -> %s" % (tg0, tg1))
+        dt = e0.elapsed_time(e1)
+        split[ph] += dt
+        per_layer.setdefault(l1 if ph != "between" else l0, {}).setdefault(ph, 0.0)
+        per_layer[l1 if ph != "between" else l0][ph] += dt
+    weights = sum(int(np.prod(l.weight.shape)) for l in q.quantized_network_layers)
+    names = {id(mod): nm for nm, mod in q.quantized_network.named_modules()}
+    for li, layer in enumerate(q.quantized_network_layers):
+        rec = per_layer.get(li, {})
+        log("%-24s %-18s " % (names[id(layer)], "x".join(str(v) for v in layer.weight.shape)) +
+            "  ".join("%s %8.2f" % (k, rec.get(k, 0.0)) for k in ("forward", "capture", "prepare", "loop", "metrics", "write_back", "between")))
+    total_ev = sum(split.values())
+    out = {"metric": "QuantizeNeuralNet.quantize_network() wall time, %s all %d layers, calib batch %d (what main.py:120-125 times)"
+                     % (name, len(q.quantized_network_layers), batch),
+           "value": round(wall, 4), "unit": "s", "higher_is_better": False, "n_gpus": 1, "dtype": "f32",
+           "data": "synthetic (random-init weights, random images)",
+           "config": {"workload": "%s (builder-owned architecture, arch.py), 4-bit, scalar 1.16, retain_rate 0.25, batch %d" % (name, batch),
+                      "layers": len(q.quantized_network_layers), "weights": weights},
+           "weights_per_s_wall_M": round(weights / wall / 1e6, 3),
+           "split_ms": {k: round(v, 2) for k, v in split.items()},
+           "split_share": {k: round(v / total_ev, 4) for k, v in split.items()},
+           "events_cover_ms": round(total_ev, 2),
+           "loop_only_M_weights_per_s": round(weights / (split["loop"] * 1e-3) / 1e6, 2),
+           "cooperative_timeouts": sum(len(r["timeouts"]) for r in q.layer_reports),
+           "relative_quantize_error_range": [round(min(r["relative_quantize_error"] for r in q.layer_reports), 5),
+                                             round(max(r["relative_quantize_error"] for r in q.layer_reports), 5)]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.driver:
+        return driver_bench(args)
     if args.capture and (args.max_cols or args.distinct_shapes):
         sys.exit("bench.py: --capture takes the full layers (no --max-cols / --distinct-shapes)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -4,8 +4,8 @@
     python -m quantized_neural_nets_amd.main -model alexnet -b 4 -bs 32 -s 1.16 --synthetic
 
 Models come from torchvision when it is installed (pretrained=True needs its checkpoint cache); without
-torchvision only `alexnet` is available, as a randomly initialised copy of the architecture, which together with
---synthetic (random calibration batches instead of the ImageNet loader) is enough to run the whole plumbing.
+torchvision `alexnet`, `resnet18` and `resnet50` are available as randomly initialised copies of the architectures
+(arch.py), which together with --synthetic (random calibration batches instead of the ImageNet loader) is enough to run the whole plumbing.
 Like the reference, every run appends one row to a CSV log (main.py:166-177; same 20 columns, written with the
 header when the file is new) and, with --save_dir, saves the quantized nn.Module under the reference's file name
 (main.py:127-136).  Accuracy columns are evaluated when a test loader exists (main.py:138-159); with --synthetic
@@ -86,7 +86,10 @@ def load_model(name, data_set='ILSVRC2012'):
     except ImportError:
         if name == 'alexnet':
             return AlexNetArch(), False
-        raise SystemExit("torchvision is not installed: only `-model alexnet` (random init) is available")
+        from .arch import ARCHITECTURES
+        if name in ARCHITECTURES:                   # builder-owned ResNet-18 / ResNet-50 definitions, random init
+            return ARCHITECTURES[name](), False
+        raise SystemExit("torchvision is not installed: only `-model alexnet`, `resnet18` and `resnet50` (random init) are available")
 
 
 class SyntheticLoader:

@@ -83,6 +83,11 @@ class QuantizeNeuralNet:
         # the headline, 422 -> 362 on an 8-GPU rank's rows).  -- extra
         self.prefetch_analog = False
         self.stochastic_seed_base = 0   # layer i of this run draws Philox streams keyed by base + i -- extra
+        # Optional callable(tag, layer_idx) invoked at the phase boundaries of every layer -- layer_begin, forward_begin /
+        # capture_begin / capture_end (twice: analog, quantized network), prepare_begin / loop_begin / loop_end (the
+        # native call), metrics_end, layer_end -- so that a profiler can record stream events there (bench.py --driver:
+        # what main.py:120-125 times, split).  -- extra
+        self.timing_hook = None
         self.layer_reports = []     # per-layer dicts (index, errors, step) -- extra, not in the reference
         self.layer_indices = []     # per-layer alphabet indices + step, what packed.save() writes -- extra
 
@@ -98,6 +103,7 @@ class QuantizeNeuralNet:
         if self.prefetch_analog and torch.cuda.is_available() and torch.device(self.device).type == 'cuda':
             side = torch.cuda.Stream(device=self.device)
         for done, layer_idx in enumerate(todo):
+            self._mark("layer_begin", layer_idx)
             gc.collect()
             if ahead is not None and ahead[0] == layer_idx:
                 _, raw, save_input = ahead
@@ -133,7 +139,10 @@ class QuantizeNeuralNet:
             res = StepAlgorithm._quantize_layer_ex(W, analog_in, quantized_in, analog_in.shape[0], step_size, K, pct,
                                                    self.reg, self.lamb, groups, self.stochastic_quantization,
                                                    self.device, plan=self.plan,
-                                                   seed=self.stochastic_seed_base + done)
+                                                   seed=self.stochastic_seed_base + done,
+                                                   event_hook=(lambda tag, shape, li=layer_idx: self._mark(tag, li))
+                                                   if self.timing_hook else None)
+            self._mark("metrics_end", layer_idx)
             Q, quantize_error, relative_quantize_error = res["Q"], res["quantize_error"], res["relative_quantize_error"]
             quantize_adder, relative_adder = res["quantize_adder"], res["relative_adder"]
             Q = Q.float() if W_shape is None else Q.reshape(W_shape).float()
@@ -157,7 +166,12 @@ class QuantizeNeuralNet:
 
             del analog_in, quantized_in
             gc.collect()
+            self._mark("layer_end", layer_idx)
         return self.quantized_network
+
+    def _mark(self, tag, layer_idx):
+        if self.timing_hook is not None:
+            self.timing_hook(tag, layer_idx)
 
     def _log_layer(self, layer_idx, W, Q, quantize_adder, relative_adder):
         '''Optional .npy dumps of W, Q, U^T and the per-neuron relative error (quantize_neural_net.py:199-209).'''
@@ -179,6 +193,16 @@ class QuantizeNeuralNet:
         raise TypeError(f'The layer type {type(analog_layer)} is not currently supported')
 
     def _forward_to(self, net, layer, hook, raw_input_data):
+        if self.timing_hook is not None:
+            inner, li = hook, self._layer_index_of(layer)
+
+            def hook(module, module_in, module_out):
+                self._mark("capture_begin", li)
+                try:
+                    return inner(module, module_in, module_out)
+                finally:
+                    self._mark("capture_end", li)
+            self._mark("forward_begin", li)
         handle = layer.register_forward_hook(hook)
         try:
             with torch.no_grad():
@@ -187,6 +211,13 @@ class QuantizeNeuralNet:
             pass
         finally:
             handle.remove()
+
+    def _layer_index_of(self, layer):
+        for layers in (self.analog_network_layers, self.quantized_network_layers):
+            for i, l in enumerate(layers):
+                if l is layer:
+                    return i
+        return -1
 
     def _capture_analog(self, layer_idx, side_stream):
         '''First half of quantize_neural_net.py:217-274: the NEXT batch of the loader through the analog network, cut at

@@ -304,7 +304,7 @@ class StepAlgorithm:
         idx_dtype, idx_bytes = _idx_dtype(K)
         dev = W.device
         st = _lib.current_stream_ptr(dev)
-        scr = _lib.scratch(dev)
+        scr = None                                   # taken under the device's lock, below
 
         def run_rows(W_loc, groups_loc, A_loc, lda_loc, X_loc, ldx_loc, row_id0):
             """all groups of a (sub)layer in one launch; returns Q, idx, U for those rows"""
@@ -365,12 +365,17 @@ class StepAlgorithm:
 
         timeouts = []
         shard = _dist.active()
-        if shard is None:
-            Q, idx, U, usq_seg = run_rows(W, groups, A, lda, X, ldx, 0)
-            rows = None
-        else:
-            Q, idx, U, usq_seg, rows = _dist.quantize_sharded(shard, W, A, lda, X, ldx, groups, dg, step, K, mode,
-                                                              lamb_f, idx_dtype, run_rows)
+        # scratch -> launches -> status reads under the device's lock (_lib.exclusive): the scratch area, its granules and
+        # its status words are one per device, and two host threads on two streams must neither run two cooperative grids
+        # on them at once nor read each other's timeout
+        with _lib.exclusive(dev):
+            scr = _lib.scratch(dev)
+            if shard is None:
+                Q, idx, U, usq_seg = run_rows(W, groups, A, lda, X, ldx, 0)
+                rows = None
+            else:
+                Q, idx, U, usq_seg, rows = _dist.quantize_sharded(shard, W, A, lda, X, ldx, groups, dg, step, K, mode,
+                                                                  lamb_f, idx_dtype, run_rows)
         out = dict(Q=Q, idx=idx, U=U, usq_seg=usq_seg, step=step_t, rows=rows, timeouts=timeouts)
         if compute_errors:
             out.update(StepAlgorithm._error_metrics(W, A, usq_seg, groups, rows, shard, U))

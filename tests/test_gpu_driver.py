@@ -289,3 +289,49 @@ def test_cooperative_launches_on_two_streams_are_serialised():
     _lib.check_status(dev)                           # raises if either launch gave up waiting for a peer workgroup
     for r, q in zip(ref, out):
         assert torch.equal(r["idx"], q["idx"]) and torch.equal(r["U"], q["U"])
+
+
+def test_cooperative_layers_from_two_host_threads_keep_their_granules_and_status_apart():
+    """Two HOST THREADS, each on a stream of its own, each quantizing chip-filling cooperative layers through the default
+    surface (status read behind every launch): the scratch area -- exchange granules and status words -- is one per device,
+    so `scratch() -> launch -> status read` runs under the device's lock (_lib.exclusive).  Without it both threads can
+    pass scratch() before either launches: two grids on the same granules, one thread's memset under the other's exchange,
+    either thread consuming the other's timeout.  Both threads must return the serial results, with no timeout."""
+    import threading
+    from quantized_neural_nets_amd import StepAlgorithm as SA, _lib
+    import bench_workload as bw
+    dev = torch.device("cuda:0")
+    N, d, m = 64, 48, 93184
+    assert _lib.describe_plan(N, d, m).startswith("coop")
+    layers = []
+    for seed in range(21, 27):
+        W, A, X = bw.synthetic_layer(N, d, m, seed, first_layer=False)
+        layers.append((W.to(dev), A.to(dev), X.to(dev), bw.layer_step(W)))
+    ref = [SA._quantize_layer_ex(W, A, X, m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev, compute_errors=False, step_override=st)
+           for W, A, X, st in layers]
+    torch.cuda.synchronize()
+    out, errors = {}, []
+    start = threading.Barrier(2)
+
+    def worker(which):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            start.wait()
+            with torch.cuda.stream(s):
+                for i in range(which, len(layers), 2):
+                    W, A, X, st = layers[i]
+                    out[i] = SA._quantize_layer_ex(W, A, X, m, 1.16 / 8, 8, 1, None, 0.1, 1, False, dev, compute_errors=False,
+                                                   step_override=st)
+            s.synchronize()
+        except Exception as e:                       # noqa: BLE001  (reported by the main thread)
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    _lib.check_status(dev)
+    for i, r in enumerate(ref):
+        assert out[i]["timeouts"] == [] and torch.equal(r["idx"], out[i]["idx"]) and torch.equal(r["U"], out[i]["U"])

@@ -1,0 +1,85 @@
+"""quantize_network() on REAL block architectures at config scale (BASELINE.json configs 1 and 3): builder-owned ResNet-18
+(BasicBlock) at calibration batch 256 and ResNet-50 (Bottleneck: downsample conv registered -- and quantized -- after
+conv3, reference utils.py:87-93) -- strided 3x3 convs, 1x1 stride-2 downsample convs, the 7x7 stem, the fc -- through
+extract_layers' block whitelist and the capture hooks (reference quantize_neural_net.py:136-193, :217-274, :325-350).
+
+For every DISTINCT layer shape the indices the driver produced for the layer's first and last rows are compared with the
+CPU oracle run on the very inputs the hooks captured for that layer in that run; and the whole run is repeated with the
+capture going through F.unfold + index_select (the reference's own op sequence) instead of the fused gather kernel: every
+quantized weight must be bit-equal (same batches, same numpy draws, same hook order, same write-back)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _run(model_name, batch, fused, oracle_mod=None, seed=0, max_check_cols=24):
+    import quantized_neural_nets_amd.quantize_neural_net as qnn_mod
+    from quantized_neural_nets_amd import QuantizeNeuralNet, StepAlgorithm, arch
+    from quantized_neural_nets_amd.main import SyntheticLoader
+    from quantized_neural_nets_amd.step_algorithm import PreparedColumns
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = arch.ARCHITECTURES[model_name]().to(DEV).eval()
+    q = QuantizeNeuralNet(model, model_name, batch, SyntheticLoader(batch, 224, seed + 1), mlp_bits=4, cnn_bits=4,
+                          ignore_layers=[], mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16, mlp_percentile=1,
+                          cnn_percentile=1, reg=None, lamb=0.1, retain_rate=0.25, stochastic_quantization=False,
+                          device=torch.device(DEV))
+    real = StepAlgorithm._quantize_layer_ex
+    seen, stats = set(), dict(shapes=0, weights=0, mismatches=0, calls=0)
+
+    def checked(W, A, X, m, step_size, K, pct, reg, lamb, groups, stochastic, device, **kw):
+        res = real(W, A, X, m, step_size, K, pct, reg, lamb, groups, stochastic, device, **kw)
+        stats["calls"] += 1
+        key = (tuple(W.shape), int(m), int(groups))
+        if oracle_mod is not None and key not in seen:
+            seen.add(key)
+            N, d = W.shape
+            rows = sorted(set(list(range(min(N, 4))) + list(range(max(N - 4, 0), N))))
+            cols = min(d, max_check_cols)
+            Am = A.matrix() if isinstance(A, PreparedColumns) else A
+            Xm = X.matrix() if isinstance(X, PreparedColumns) else X
+            assert Am.shape == (m, d) and Xm.shape == (m, d)
+            ridx = torch.tensor(rows, device=W.device)
+            _, idx_o, _ = oracle_mod.quantization(W.index_select(0, ridx)[:, :cols].cpu().numpy(), Am[:, :cols].cpu().numpy(),
+                                                  Xm[:, :cols].cpu().numpy(), float(res["step"]), K)
+            got = res["idx"].index_select(0, ridx)[:, :cols].cpu().numpy().astype(np.int16)
+            stats["shapes"] += 1
+            stats["weights"] += got.size
+            stats["mismatches"] += int((got != idx_o).sum())
+        return res
+
+    old_fused = qnn_mod.FUSED_CAPTURE
+    qnn_mod.FUSED_CAPTURE = fused
+    StepAlgorithm._quantize_layer_ex = checked
+    try:
+        q.quantize_network()
+    finally:
+        StepAlgorithm._quantize_layer_ex = real
+        qnn_mod.FUSED_CAPTURE = old_fused
+    torch.cuda.synchronize()
+    return q, stats
+
+
+@pytest.mark.parametrize("model_name,batch,nlayers", [("resnet18", 256, 21), ("resnet50", 32, 54)])
+def test_block_architecture_through_the_driver(model_name, batch, nlayers, oracle_mod, capsys):
+    q, stats = _run(model_name, batch, True, oracle_mod)
+    assert len(q.quantized_network_layers) == nlayers == stats["calls"] == len(q.layer_reports)
+    assert stats["shapes"] >= (12 if model_name == "resnet18" else 20) and stats["mismatches"] == 0, stats
+    for rep in q.layer_reports:
+        assert rep["timeouts"] == [] and np.isfinite(rep["relative_quantize_error"]) and 0 < rep["relative_quantize_error"] < 1.5
+    # every layer landed on the 17-level alphabet of its own step, biases / BatchNorm untouched, analog network untouched
+    for li, (qa, an) in enumerate(zip(q.quantized_network_layers, q.analog_network_layers)):
+        rec = q.layer_indices[li]
+        k = qa.weight.detach().reshape(qa.weight.shape[0], -1) / rec["step"]
+        assert torch.equal(torch.round(k).to(torch.int8).cpu(), rec["idx"].to(torch.int8)) and int(rec["idx"].abs().max()) <= 8
+        assert not torch.equal(qa.weight, an.weight)
+    out = capsys.readouterr().out
+    assert "Quantizing layer with index: %d" % (nlayers - 1) in out
+    # the same run with the reference's capture op sequence (unfold, transpose, reshape, index) instead of the fused gather
+    q2, _ = _run(model_name, batch, False)
+    for a, b in zip(q.quantized_network_layers, q2.quantized_network_layers):
+        assert torch.equal(a.weight, b.weight)
