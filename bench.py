@@ -401,7 +401,8 @@ def driver_bench(args):
       loop        the GPFQ loop kernels (step_algorithm.py:140-148)
       metrics     status read + error metrics (one A @ W.T GEMM, :216-219)
       write_back  Q into the quantized network, the two printed errors (.cpu(): a sync), the index copy for packed.save
-      between     host work between layers: gc.collect (:211-212), the loader's next batch, prints
+      between     host work between layers: the loader's next batch, prints (the reference's three gc.collect() per layer,
+                  :137 / :212 / :271, are off by default here: quantize_neural_net.COLLECT_GARBAGE_PER_LAYER)
     Random-init weights and random images (no checkpoints, no ImageNet here): the loop's cost does not depend on values."""
     import contextlib
     import numpy as np
@@ -415,7 +416,8 @@ def driver_bench(args):
     torch.manual_seed(0)
     np.random.seed(0)
     model = arch.ARCHITECTURES[name]().to(dev).eval()
-    q = QuantizeNeuralNet(model, name, batch, SyntheticLoader(batch, 224, 1), mlp_bits=4, cnn_bits=4, ignore_layers=[],
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("GPFQ_DRIVER_CONV_BENCHMARK", "0")))
+    q = QuantizeNeuralNet(model, name, batch, SyntheticLoader(batch, 224, 1, device=dev), mlp_bits=4, cnn_bits=4, ignore_layers=[],
                           mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16, mlp_percentile=1, cnn_percentile=1, reg=None,
                           lamb=0.1, retain_rate=0.25, stochastic_quantization=False, device=dev)
     # one untimed forward of a full batch: the convolution library picks (and, on a fresh box, builds) its kernels here
@@ -454,6 +456,7 @@ def driver_bench(args):
         split[ph] += dt
         per_layer.setdefault(l1 if ph != "between" else l0, {}).setdefault(ph, 0.0)
         per_layer[l1 if ph != "between" else l0][ph] += dt
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     weights = sum(int(np.prod(l.weight.shape)) for l in q.quantized_network_layers)
     names = {id(mod): nm for nm, mod in q.quantized_network.named_modules()}
     for li, layer in enumerate(q.quantized_network_layers):
@@ -473,6 +476,9 @@ def driver_bench(args):
            "events_cover_ms": round(total_ev, 2),
            "loop_only_M_weights_per_s": round(weights / (split["loop"] * 1e-3) / 1e6, 2),
            "cooperative_timeouts": sum(len(r["timeouts"]) for r in q.layer_reports),
+           "peak_device_memory_GiB": round(peak_gb, 2),
+           "loader": "synthetic batches drawn on the device (no host time, no copy); conv algorithm search %s" % (
+               "on (cudnn.benchmark)" if torch.backends.cudnn.benchmark else "off"),
            "relative_quantize_error_range": [round(min(r["relative_quantize_error"] for r in q.layer_reports), 5),
                                              round(max(r["relative_quantize_error"] for r in q.layer_reports), 5)]}
     print(json.dumps(out), flush=True)

@@ -1,7 +1,8 @@
 // gpfq_capi.hip -- host side of the MI355X GPFQ hot path: plan selection, launches and the C ABI of include/gpfq.h.
 //
 // Path (reference = YixuanSeanZhou/Quantized_Neural_Nets, src/):
-//   StepAlgorithm._quantization   step_algorithm.py:107-148   -> gpfq_loop_kernels.h (resident / coop / wave / stream kernels)
+//   StepAlgorithm._quantization   step_algorithm.py:107-148   -> gpfq_loop_kernels.h (resident / coop / wave / stream kernels),
+//                                                                 gpfq_pipe_kernels.h (pipelined cooperative kernels)
 //   quantizers                    step_algorithm.py:7-104     -> gpfq_device.h quant_*
 //   column reads [:, t], norm     step_algorithm.py:141-144   -> gpfq_prep_kernels.h
 //   conv activation capture       quantize_neural_net.py:334-347 -> gpfq_prep_kernels.h gpfq_gather_patches_kernel
@@ -11,11 +12,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/gpfq.h"
 #include "gpfq_device.h"
 #include "gpfq_loop_kernels.h"
+#include "gpfq_pipe_kernels.h"
 #include "gpfq_prep_kernels.h"
 
 // ================================================================================================
@@ -56,6 +59,7 @@ struct Plan {
     int rounds;    // coop: launches the rows are spread over (every launch must be co-resident); 1 = all rows at once
     int tiles_round;   // coop: row tiles per launch
     int grouped;   // coop: one row per group (depthwise convolutions), every row with its own columns
+    int pipe;      // coop: the PIPELINED kernels (gpfq_pipe_kernels.h): RT = 4 or 8 rows in four groups, reducer wave of its own
 };
 
 int device_cu_count()
@@ -183,6 +187,8 @@ double stream_col_cost(int64_t Ng, int S, int cus)
 // chip, one launch per block, every launch walking all d columns with its block of U in registers (the columns come
 // from L2 / the Infinity Cache again; U, the 8*N*m bytes per column of the streaming plan, never moves).
 // Depends on (Ng, S, CU count) only -- never on the data.  cost_out: microseconds per column for all rows.
+bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out, bool allow_rounds);
+
 bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out = nullptr, bool allow_rounds = true)
 {
     const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
@@ -221,7 +227,69 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
                 found = true;
                 best = cost;
                 pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
-                pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0;
+                pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0; pl->pipe = 0;
+            }
+        }
+    }
+    // the pipelined kernels where they are modelled cheaper (GPFQ_COOP_PIPE: 0 never, 1 whenever a configuration exists)
+    const int pipe_mode = env_int("GPFQ_COOP_PIPE", -1);
+    if (pipe_mode != 0) {
+        Plan pp = *pl;
+        double pcost = 0.0;
+        if (choose_pipe(Ng, S, cus, mode, &pp, &pcost, allow_rounds) && (!found || pipe_mode == 1 || pcost < best)) {
+            *pl = pp;
+            best = pcost;
+            found = true;
+        }
+    }
+    if (found && cost_out) *cost_out = best;
+    return found;
+}
+
+// One column step of the PIPELINED cooperative kernels (gpfq_pipe_kernels.h), microseconds, measured on one MI355X
+// (tools/layer_bench.py, round 4; the members of a tile on one XCD, publishing with plain stores): four phases, each the longer
+// of one group's sweep on the fullest SIMD -- RG = 2: 0.20 us per sweep wave of that SIMD + 0.13 (lane tree, LDS, barrier),
+// RG = 1: 0.13 + 0.13 -- and the gatherer wave's own phase (~0.38 us: landing of the requested granules, epoch check, tree
+// over the members, quantizer, q and history into LDS), a little longer with more sweep waves queueing column requests in
+// front of its loads and with 32+ members.  Measured / modelled per column: 8 rows x 16 members x 6 waves 2.12 / 2.12,
+// 8 x 8 x 4 1.70 / 1.68, 8 x 16 x 2 1.52 / 1.52, 8 x 32 x 3 1.73 / 1.76, 4 x 16 x 6 1.73 / 1.68.
+double pipe_step_cost(int RG, int waves, int C)
+{
+    const int per_simd = (waves + 3) / 4;                                  // sweep waves on the fullest SIMD
+    const double sweep = (RG == 1 ? 0.13 : 0.20) * per_simd + 0.13;
+    double gather = 0.38 + (waves >= 3 ? 0.04 : 0.0) + (RG * C >= 64 ? 0.02 : 0.0);
+    if (waves == 7) gather += 0.12;                                        // (one wave for both reducer roles: + the slot tree and the store)
+    return 4.0 * (sweep > gather ? sweep : gather);
+}
+
+// The pipelined configurations for (Ng rows, S segments): RT = 8 (four interleaved pairs) or 4 (four single rows), C members
+// with at most 6 segments each (6 sweep waves + the publisher + the gatherer: the 256-register budget), RG * C <= 64 granules per gather.
+bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out, bool allow_rounds)
+{
+    (void)mode;                                                            // (every quantizer has both variants)
+    const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
+    double best = 1e30;
+    bool found = false;
+    for (int RT = 8; RT >= 4; RT >>= 1) {
+        if (force_rt && RT != force_rt) continue;
+        const int RG = RT / 4;
+        const int64_t tiles = (Ng + RT - 1) / RT;
+        for (int C = 64 / RG; C >= 2; C >>= 1) {
+            if (force_c && C != force_c) continue;
+            if (C > S || C > cus) continue;
+            const int NW = (S + C - 1) / C;
+            if (NW > 7 || pow2_ceil_host(S) / C > 16) continue;
+            const int64_t tiles_round = tiles * C <= cus ? tiles : cus / C;
+            if (tiles_round < 1) continue;
+            const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
+            if (rounds > 1 && !allow_rounds) continue;
+            if ((size_t)tiles_round * 2 * C * RT * sizeof(unsigned long long) > kScratchStatusOffset) continue;
+            const double cost = (double)rounds * pipe_step_cost(RG, NW, C);
+            if (!found || cost < best - 1e-9) {
+                found = true;
+                best = cost;
+                pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
+                pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0; pl->pipe = 1;
             }
         }
     }
@@ -251,7 +319,7 @@ bool choose_coop_grouped(int groups, int S, int cus, Plan* pl, double* cost_out)
             found = true;
             best = cost;
             pl->kind = GPFQ_PLAN_COOP; pl->RT = 1; pl->C = C; pl->tiles = groups; pl->waves = NW; pl->S = S;
-            pl->rounds = rounds; pl->tiles_round = tiles_round; pl->grouped = 1;
+            pl->rounds = rounds; pl->tiles_round = tiles_round; pl->grouped = 1; pl->pipe = 0;
         }
     }
     if (found && cost_out) *cost_out = best;
@@ -267,7 +335,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
     pl->kind = GPFQ_PLAN_STREAM;
     pl->S = S;
     pl->C = 1;
-    pl->rounds = 1; pl->tiles_round = 0; pl->grouped = 0;
+    pl->rounds = 1; pl->tiles_round = 0; pl->grouped = 0; pl->pipe = 0;
     pl->RT = Ng >= 1024 ? 4 : (Ng >= 512 ? 2 : 1);
     while (pl->RT > 1 && (size_t)2 * pl->RT * S * sizeof(float) > 48 * 1024) pl->RT >>= 1;   // the segment sums of RT rows live in LDS
     if (S > 1024 && pl->RT > 2) pl->RT = 2;               // (the four-row kernel has no 32 / 64-slots-per-lane tree)
@@ -308,7 +376,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
 int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, int mode, Plan* out)
 {
     Plan pl;
-    pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0; pl.grouped = 0;
+    pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0; pl.grouped = 0; pl.pipe = 0;
     if (m_pad / gpfq::kSeg > 4096) return fail(GPFQ_ERR_UNSUPPORTED, "m > 4194304 calibration rows is not supported");
     pl.S = (int)(m_pad / gpfq::kSeg);
     if (requested < GPFQ_PLAN_AUTO || requested > GPFQ_PLAN_STREAM_ROWS) return fail(GPFQ_ERR_ARG, "unknown plan id");
@@ -359,7 +427,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
                 *out = pl;
                 return GPFQ_OK;
             }
-            pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0;
+            pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0; pl.pipe = 0;
         }
         if (requested == GPFQ_PLAN_COOP)
             return fail(GPFQ_ERR_UNSUPPORTED, "cooperative plan needs groups == 1, a scratch buffer and a shape that fits");
@@ -453,6 +521,7 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
+    sp.salt = 0; sp.allow_local = 0;                // launch_pipe sets them
     return sp;
 }
 
@@ -526,8 +595,63 @@ bool coop_variant_exists(int RT, int NW, int C, int mode)
     return coop_kernel_for(RT, NW, C, mode, false, nullptr, nullptr) != nullptr;
 }
 
+// the pipelined cooperative kernels (gpfq_pipe_kernels.h): RG = 1 (four single rows) or 2 (four interleaved pairs)
+SlabKernel pipe_kernel(int RG, int mode, bool single)
+{
+#define GPFQ_PICKP(RGV, SINGLEV, SUFFIX)                                                                              \
+    if (RG == RGV && single == SINGLEV) {                                                                             \
+        switch (mode) {                                                                                               \
+        case gpfq::MODE_SOFT: return gpfq::gpfq_pipe_rg##RGV##_m1_w8##SUFFIX;                                         \
+        case gpfq::MODE_HARD: return gpfq::gpfq_pipe_rg##RGV##_m2_w8##SUFFIX;                                         \
+        case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_pipe_rg##RGV##_m3_w8##SUFFIX;                                   \
+        default: return gpfq::gpfq_pipe_rg##RGV##_m0_w8##SUFFIX;                                                      \
+        }                                                                                                             \
+    }
+    GPFQ_PICKP(1, false, ) GPFQ_PICKP(2, false, ) GPFQ_PICKP(1, true, s) GPFQ_PICKP(2, true, s)
+#undef GPFQ_PICKP
+    return nullptr;
+}
+
+// the epoch word of a pipelined granule: column + 1 in 20 bits, the launch number in 8, the publisher's XCD in 4
+bool p_d_fits_epoch(int d) { return d < (1 << 20) - 1; }
+
+int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
+{
+    if (!p_d_fits_epoch(sp.d)) return fail(GPFQ_ERR_UNSUPPORTED, "pipelined cooperative kernels take fewer than 2^20 columns");
+    const int RT = pl.RT, RG = RT / 4;
+    const bool single = pl.waves == 7;                                 // seven sweep waves: one wave plays both reducer roles
+    SlabKernel kern = (RT == 4 || RT == 8) ? pipe_kernel(RG, mode, single) : nullptr;
+    if (!kern || pl.waves < 1 || pl.waves > 7 || RG * pl.C > 64)
+        return fail(GPFQ_ERR_UNSUPPORTED, "internal: no pipelined cooperative kernel for this (rows, waves, members) triple");
+    const int nwaves = pl.waves + (single ? 1 : 2);                    // + the publisher wave and the gatherer wave (or one for both)
+    const int threads = 64 * nwaves;
+    const size_t shm = sizeof(float) * ((size_t)RT * pl.waves + RT + 2 * (size_t)RT * 64 + 4);   // (+ the locality flag)
+    const int nblocks = pl.tiles * pl.C;
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, shm);
+    if (e != hipSuccess) return hip_fail(e, "occupancy query");
+    const int cus = device_cu_count();
+    if (nb < 1 || nblocks > cus) return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
+    size_t xbytes = (size_t)pl.tiles * 2 * pl.C * RT * sizeof(unsigned long long);
+    xbytes = (xbytes + 15) & ~(size_t)15;
+    if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
+    e = hipMemsetAsync(scratch, 0, xbytes, st);
+    if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
+    gpfq::SlabParams spx = sp;
+    spx.spin_limit = sp.spin_limit & ~255u;                            // (no pause before a gather: the granules are two phases old)
+    spx.xcd_tiles = env_int("GPFQ_COOP_XCD_TILES", 1);
+    static std::atomic<unsigned> launch_number{0};
+    spx.salt = launch_number.fetch_add(1) & 255u;
+    spx.allow_local = env_int("GPFQ_PIPE_LOCAL", 1) && p_d_fits_epoch(sp.d);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "GPFQ pipelined cooperative kernel launch");
+    return GPFQ_OK;
+}
+
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
+    if (pl.pipe) return launch_pipe(pl, sp, mode, scratch, st);
     const int RT = pl.RT;
     int maxw = 0;
     bool lds = false;
@@ -1065,11 +1189,11 @@ int gpfq_describe_plan_mode(int64_t N, int64_t d_g, int64_t m, int groups, int p
             snprintf(buf, buf_bytes, "coop RT=1 C=%d waves=%d S=%d grid=%d rounds=%d groups=%d d=%lld", pl.C, pl.waves, pl.S,
                      pl.tiles_round * pl.C, pl.rounds, groups, (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_COOP && pl.rounds > 1)
-            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d rounds=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
-                     pl.tiles_round * pl.C, pl.rounds, (long long)d_g);
+            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d rounds=%d%s d=%lld", pl.RT, pl.C, pl.waves, pl.S,
+                     pl.tiles_round * pl.C, pl.rounds, pl.pipe ? " pipe=1" : "", (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_COOP)
-            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
-                     pl.tiles * pl.C, (long long)d_g);
+            snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d%s d=%lld", pl.RT, pl.C, pl.waves, pl.S,
+                     pl.tiles * pl.C, pl.pipe ? " pipe=1" : "", (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_STREAM && pl.C > 1)
             snprintf(buf, buf_bytes, "stream RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
                      pl.tiles * pl.C, (long long)d_g);

@@ -99,6 +99,8 @@ struct SlabParams {
     float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
     unsigned spin_limit;    // cooperative kernels: 256 * (polls before an exchange gives up, host-clamped to < 2^24) + (low five bits: pause before the first poll, in units of 256 clocks, 0 .. 31)
     uint64_t seed, row_id0;
+    unsigned salt;     // pipelined kernels: 8-bit launch number carried in every granule's epoch word (a line left behind by an earlier launch never matches)
+    int allow_local;   // pipelined kernels: members of a tile that find themselves on ONE XCD may publish with plain stores (the XCD's L2 is their coherence point)
 };
 
 template <int MODE>

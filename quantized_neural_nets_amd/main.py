@@ -93,15 +93,19 @@ def load_model(name, data_set='ILSVRC2012'):
 
 
 class SyntheticLoader:
-    """Endless (images, labels) batches from a seeded generator -- the loader surface QuantizeNeuralNet needs."""
+    """Endless (images, labels) batches from a seeded generator -- the loader surface QuantizeNeuralNet needs.
+    device None: drawn on the host (bit-reproducible anywhere; 0.5 s per batch of 1024 -- the reference hides that cost
+    in DataLoader worker processes, data_loaders.py:75).  device given: drawn there by that device's generator (no host
+    time, no host-to-device copy: what a prefetching loader looks like to the driver)."""
 
-    def __init__(self, batch_size, image_size, seed):
-        self.bs, self.hw = batch_size, image_size
-        self.gen = torch.Generator().manual_seed(seed)
+    def __init__(self, batch_size, image_size, seed, device=None):
+        self.bs, self.hw, self.device = batch_size, image_size, device
+        self.gen = torch.Generator(device=device if device is not None else "cpu").manual_seed(seed)
 
     def __iter__(self):
         while True:
-            yield torch.randn(self.bs, 3, self.hw, self.hw, generator=self.gen), torch.zeros(self.bs, dtype=torch.long)
+            yield (torch.randn(self.bs, 3, self.hw, self.hw, generator=self.gen, device=self.device),
+                   torch.zeros(self.bs, dtype=torch.long))
 
 
 # the columns of the reference's log (main.py:13-14 `fields`, logs/Quantization_Log.csv), in its order

@@ -28,6 +28,13 @@ CONV2D_MODULE_TYPE = nn.Conv2d
 
 RESULT_LOGGING_DIR = 'result_logging'
 LAYER_LOGGING = False
+# The reference runs a full gc.collect() three times per layer (quantize_neural_net.py:137, :212, :271) to drop the layer
+# inputs.  Here every large tensor is released by reference counting the moment its last name goes (the aborted forward's
+# InterruptException is handled without being bound, so its traceback -- and the activations its frames hold -- dies with
+# the `except` clause; tests/test_gpu_driver_scale.py checks the peak memory), and a full collection costs ~40 ms of host
+# time in a process that has imported torch: 3 x 54 layers = 6.5 s of a 12 s ResNet-50 run (bench.py --driver r50).
+# True restores the reference's calls.
+COLLECT_GARBAGE_PER_LAYER = False
 # Conv2d capture: gather the sampled patches on the GPU straight into the kernels' column layout
 # (gpfq_gather_patches_f32) instead of materialising the full unfold and transposing it afterwards.
 FUSED_CAPTURE = True
@@ -104,7 +111,8 @@ class QuantizeNeuralNet:
             side = torch.cuda.Stream(device=self.device)
         for done, layer_idx in enumerate(todo):
             self._mark("layer_begin", layer_idx)
-            gc.collect()
+            if COLLECT_GARBAGE_PER_LAYER:
+                gc.collect()
             if ahead is not None and ahead[0] == layer_idx:
                 _, raw, save_input = ahead
             else:
@@ -165,7 +173,8 @@ class QuantizeNeuralNet:
                 self._log_layer(layer_idx, W, Q, quantize_adder, relative_adder)
 
             del analog_in, quantized_in
-            gc.collect()
+            if COLLECT_GARBAGE_PER_LAYER:
+                gc.collect()
             self._mark("layer_end", layer_idx)
         return self.quantized_network
 
@@ -254,7 +263,8 @@ class QuantizeNeuralNet:
         raw_input_data, save_input = self._capture_analog(layer_idx, None)
         self._capture_quantized(layer_idx, raw_input_data, save_input)
         del raw_input_data
-        gc.collect()
+        if COLLECT_GARBAGE_PER_LAYER:
+            gc.collect()
         return (save_input.inputs[0], save_input.inputs[1])
 
 

@@ -21,6 +21,11 @@ def _run(model_name, batch, fused, oracle_mod=None, seed=0, max_check_cols=24):
     from quantized_neural_nets_amd import QuantizeNeuralNet, StepAlgorithm, arch
     from quantized_neural_nets_amd.main import SyntheticLoader
     from quantized_neural_nets_amd.step_algorithm import PreparedColumns
+    # The driver's result is a function of the forwards' BITS, and the convolution library's default algorithm choice is
+    # not reproducible run to run (measured: ResNet-50's layer2.0.conv2, a strided 3x3, gives the analog network another
+    # low-order bit pattern in a second identical run -- tools/scratch/diag_driver_repro.py); two runs can only be compared
+    # bit for bit with the deterministic algorithms selected.
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
     torch.manual_seed(seed)
     np.random.seed(seed)
     model = arch.ARCHITECTURES[model_name]().to(DEV).eval()
@@ -66,7 +71,12 @@ def _run(model_name, batch, fused, oracle_mod=None, seed=0, max_check_cols=24):
 
 @pytest.mark.parametrize("model_name,batch,nlayers", [("resnet18", 256, 21), ("resnet50", 32, 54)])
 def test_block_architecture_through_the_driver(model_name, batch, nlayers, oracle_mod, capsys):
+    torch.cuda.reset_peak_memory_stats()
     q, stats = _run(model_name, batch, True, oracle_mod)
+    # no full garbage collection per layer (COLLECT_GARBAGE_PER_LAYER is off): the aborted forwards' activations and the
+    # previous layers' inputs must be gone by reference counting alone -- the peak stays near one layer's working set
+    # (ResNet-18 at batch 256: the 0.8 GB of the stem's output and its BN / ReLU copies dominate)
+    assert torch.cuda.max_memory_allocated() < (12 << 30), torch.cuda.max_memory_allocated() / 2 ** 30
     assert len(q.quantized_network_layers) == nlayers == stats["calls"] == len(q.layer_reports)
     assert stats["shapes"] >= (12 if model_name == "resnet18" else 20) and stats["mismatches"] == 0, stats
     for rep in q.layer_reports:

@@ -33,6 +33,16 @@ for a in sys.argv[1:]:
     if desc.startswith("resident"):
         names = ["loop bookkeeping, last quarter of the loads, history", "wait for column t (vmcnt)", "sweeps", "first quarter of the loads, lane trees, LDS write, second quarter",
                  "barrier", "third quarter, LDS read, slot tree, divisions, quantizer, readlanes", "-", "-"]
-    for w, off in (("wave0", 0), ("lastwave", 8)):
+    who = (("wave0", 0), ("lastwave", 8))
+    if "pipe=1" in desc:
+        # pipelined cooperative kernels: cycles per PHASE (four phases per step), reducer wave and sweep wave 0 of workgroup 0
+        dl = 4 * dl
+        who = (("reducer", 0), ("sweep0", 8))
+        who = (("gatherer", 0), ("sweep0", 8))
+        rn = ["barrier", "requested gather lands", "re-polls", "next request", "tree + quantizer + q to LDS", "-", "PUBLISHER barrier", "PUBLISHER slot tree + publish"]
+        sn = ["barrier", "q from LDS + column wait", "sweep", "lane tree + LDS", "column / weight requests", "-", "-", "-"]
+    for w, off in who:
+        if "pipe=1" in desc:
+            names = rn if off == 0 else sn
         tot = sum(dbg[off:off + 8])
         print("  %-8s total %.0f cyc/step (clock %.2f GHz):" % (w, tot / dl, tot / dl / (ms * 1e3 / dl) / 1e3), "  ".join("%s %.0f" % (names[i], dbg[off + i] / dl) for i in range(8)))
