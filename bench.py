@@ -274,6 +274,8 @@ def kernel_name(desc, mode=0):
             return "gpfq_resident_rt%d_m%d_w1" % (rt, mode)
         return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
+        if kv.get("pipe") == "1":                   # the pipelined kernels: four groups of RT / 4 rows; 7 sweep waves: one reducer wave
+            return "gpfq_pipe_rg%d_m%d_w8%s" % (rt // 4, mode, "s" if waves == 7 else "")
         if "groups" in kv:                          # one row per group (depthwise convolutions)
             return "gpfq_coop_rt1g_m%d_w12" % mode
         if rt == 1:
@@ -760,8 +762,8 @@ def main():
         prep_ms_total += pm
         loop_ms_total += lm
         coll_ms_total += rec["coll_ms"] / rec["n"]
-        row = ("%-22s N=%4d d=%5d g=%4d m=%6d %-26s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg = %5.1f%% of 8 TB/s HBM%s)  prep %7.3f ms"
-               % (name, N, dg, groups, m, " ".join(desc.split()[:3]) + (" x%d" % plan_rounds(desc) if plan_rounds(desc) > 1 else ""), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
+        row = ("%-22s N=%4d d=%5d g=%4d m=%6d %-30s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg = %5.1f%% of 8 TB/s HBM%s)  prep %7.3f ms"
+               % (name, N, dg, groups, m, " ".join(desc.split()[:3]) + (" pipe" if "pipe=1" in desc else "") + (" x%d" % plan_rounds(desc) if plan_rounds(desc) > 1 else ""), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
                   "" if l2b is None else "; %5.0f GB/s L2 columns = %4.1f%% of 34.5 TB/s" % (l2b / lm / 1e6, l2b / lm / 1e6 / L2_PEAK_GBPS * 100),
                   pm))
         table.append(row)

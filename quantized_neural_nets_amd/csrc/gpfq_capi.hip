@@ -253,12 +253,17 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
 // over the members, quantizer, q and history into LDS), a little longer with more sweep waves queueing column requests in
 // front of its loads and with 32+ members.  Measured / modelled per column: 8 rows x 16 members x 6 waves 2.12 / 2.12,
 // 8 x 8 x 4 1.70 / 1.68, 8 x 16 x 2 1.52 / 1.52, 8 x 32 x 3 1.73 / 1.76, 4 x 16 x 6 1.73 / 1.68.
-double pipe_step_cost(int RG, int waves, int C)
+// `local`: the tile's members sit on one XCD (launch_pipe places them so when the tile count is a multiple of the XCDs and
+// a tile has no more members than an XCD has CUs) and publish with plain stores; otherwise every granule is a write-through
+// and a phase cannot be shorter than what its round trip needs (measured 0.53-0.60 us per phase before XCD-local
+// publishing: 2.1-2.4 us per column).
+double pipe_step_cost(int RG, int waves, int C, bool local)
 {
     const int per_simd = (waves + 3) / 4;                                  // sweep waves on the fullest SIMD
     const double sweep = (RG == 1 ? 0.13 : 0.20) * per_simd + 0.13;
     double gather = 0.38 + (waves >= 3 ? 0.04 : 0.0) + (RG * C >= 64 ? 0.02 : 0.0);
     if (waves == 7) gather += 0.12;                                        // (one wave for both reducer roles: + the slot tree and the store)
+    if (!local && gather < 0.60) gather = 0.60;
     return 4.0 * (sweep > gather ? sweep : gather);
 }
 
@@ -284,7 +289,8 @@ bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
             const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
             if (rounds > 1 && !allow_rounds) continue;
             if ((size_t)tiles_round * 2 * C * RT * sizeof(unsigned long long) > kScratchStatusOffset) continue;
-            const double cost = (double)rounds * pipe_step_cost(RG, NW, C);
+            const bool local = C <= cus / 8 && (tiles_round & 7) == 0 && env_int("GPFQ_PIPE_LOCAL", 1);
+            const double cost = (double)rounds * pipe_step_cost(RG, NW, C, local);
             if (!found || cost < best - 1e-9) {
                 found = true;
                 best = cost;

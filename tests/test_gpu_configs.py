@@ -24,7 +24,7 @@ CASES = [
     ("effnet_b1_depthwise_b1024", 8, 9, bw.conv_m(1024, 112, 3, 1), 8, 2, "L1", 0.1, "coop RT=1 C=32 waves=12 S=362 grid=256 rounds=1 groups=8"),   # m = 370 688, N_g = 1
     ("effnet_b1_depthwise5_b1024", 12, 25, bw.conv_m(1024, 14, 5, 2), 12, 2, "L1", 0.1, "resident"),
     ("effnet_b1_se_reduce_b1024", 24, 96, 1024, 1, 2, "L1", 0.1, "resident"),         # 1x1 conv on a 1x1 map: m = B
-    ("effnet_b1_project_b1024", 40, 60, bw.conv_m(1024, 28, 1, 0), 1, 2, "L1", 0.1, "coop RT=4 C=16 waves=13"),    # m = 201 728: four rows x 13 sweep waves, columns through LDS
+    ("effnet_b1_project_b1024", 40, 60, bw.conv_m(1024, 28, 1, 0), 1, 2, "L1", 0.1, "coop RT=8 C=32 waves=7 S=197 grid=160 pipe=1"),    # m = 201 728: the pipelined kernel, eight rows x 32 members, one wave for both reducer roles (round 4; before: four rows x 13 sweep waves, columns through LDS -- tests/test_gpu_rounds.py keeps that kernel covered)
 ]
 
 

@@ -66,12 +66,18 @@ def test_full_size_layer_against_oracle(oracle_mod):
     assert np.array_equal(r["U"].cpu().numpy(), U)
 
 
-@pytest.mark.parametrize("shape,kernel", [((128, 1152, 93184), "coop RT=4 C=8"), ((256, 2304, 26624), "coop RT=4 C=4")])
-def test_full_size_four_row_cooperative_shapes(oracle_mod, shape, kernel):
-    """ResNet-50 layer2.0.conv2 and layer3.0.conv2 at batch 1024 -- the two headline shapes the four-row cooperative
-    kernels carry -- at FULL d: AUTO == streaming bit for bit (indices, Q, U), the fused sum-of-squares epilogue
+@pytest.mark.parametrize("shape,kernel,pipe", [((128, 1152, 93184), "coop RT=8 C=16 waves=6 S=91 grid=256 pipe=1", None),
+                                               ((256, 2304, 26624), "coop RT=8 C=8 waves=4 S=26 grid=256 pipe=1", None),
+                                               ((128, 1152, 93184), "coop RT=4 C=8 waves=12", "0"),
+                                               ((256, 2304, 26624), "coop RT=4 C=4 waves=7", "0")])
+def test_full_size_four_row_cooperative_shapes(oracle_mod, monkeypatch, shape, kernel, pipe):
+    """ResNet-50 layer2.0.conv2 and layer3.0.conv2 at batch 1024 -- the two headline shapes with the most rows per
+    cooperative workgroup: the pipelined eight-row kernels AUTO picks since round 4, and the lock-step four-row kernels
+    (GPFQ_COOP_PIPE=0) -- at FULL d: == streaming bit for bit (indices, Q, U), the fused sum-of-squares epilogue
     equals a pass over U, and the first 256 columns equal the CPU oracle bit for bit."""
     from quantized_neural_nets_amd import _lib
+    if pipe is not None:
+        monkeypatch.setenv("GPFQ_COOP_PIPE", pipe)
     assert _lib.describe_plan(*shape).startswith(kernel), _lib.describe_plan(*shape)
     W, A, X, full = _layer(0, shape, 1234 + 11)
     assert full["timeouts"] == []

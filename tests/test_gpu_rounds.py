@@ -1,4 +1,7 @@
-"""Long rows with more rows than the chip holds at once: the cooperative plan in ROUNDS (one co-resident launch per block
+"""(Round 4: AUTO gives many of these shapes to the pipelined kernels, tests/test_gpu_pipe.py; the cases below that are about
+a particular LOCK-STEP kernel pin that family with GPFQ_COOP_PIPE=0 -- those kernels remain the choice wherever a tile has
+more than 64 granules per gather, more than seven segments per member, one or two rows, or one row per group.)
+Long rows with more rows than the chip holds at once: the cooperative plan in ROUNDS (one co-resident launch per block
 of rows, the residual of the block in registers for all d columns) against the CPU oracle and against the streaming
 plan, bit for bit -- including the gather of more than 64 granules (two members per lane) and the two-row 16-wave
 variant that m = 803 840 (785 segments, 12.3 per member at 64 members) needs.  Shapes are the 1x1 convolutions of
@@ -32,9 +35,9 @@ CASES = [
     ((70, 16, 201728), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "32"}, "coop RT=4 C=32 waves=7 S=197 grid=256 rounds=3",
      "128 granules: two gathered members per lane; the last tile has 2 valid rows"),
     ((21, 10, 803840), {"GPFQ_COOP_RT": "2"}, "coop RT=2 C=64 waves=13 S=785 grid=256 rounds=3", "16-wave variant AND 128 granules, odd row count"),
-    ((300, 24, 51200), {}, "coop RT=4 C=4 waves=13 S=50 grid=256 rounds=2",
+    ((300, 24, 51200), {"GPFQ_COOP_PIPE": "0"}, "coop RT=4 C=4 waves=13 S=50 grid=256 rounds=2",
      "four rows x 13 sweep waves, columns staged through LDS (global_load_lds); 256 rows per round, the last round partial"),
-    ((70, 16, 201728), {}, "coop RT=4 C=16 waves=13 S=197 grid=256 rounds=2", "the same variant with 16 members (64 granules)"),
+    ((70, 16, 201728), {"GPFQ_COOP_PIPE": "0"}, "coop RT=4 C=16 waves=13 S=197 grid=256 rounds=2", "the same variant with 16 members (64 granules)"),
     ((21, 10, 803840), {}, "coop RT=4 C=64 waves=13 S=785 grid=256 rounds=2",
      "the same variant with 64 members: 256 granules gathered four per lane; 16 rows per round, 5 in the last"),
     ((20, 10, 720384), {"GPFQ_COOP_RT": "2"}, "coop RT=2 C=64 waves=11 S=704 grid=256 rounds=3", "128 granules at 64 members (VGG-16 conv1 rows)"),
@@ -42,7 +45,7 @@ CASES = [
      "the LDS-staged 64-member kernel with fewer than 13 sweep waves (VGG-16 conv1 rows: 11 segments per member)"),
     ((9, 6, 530000), {}, "coop RT=4 C=64 waves=9 S=518 grid=192",
      "the same with 9 sweep waves, members of 8 and 9 segments, one round with a partial last tile"),
-    ((70, 12, 263168), {}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
+    ((70, 12, 263168), {"GPFQ_COOP_PIPE": "0"}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
     ((12, 6, 1440768), {}, "coop RT=2 C=128 waves=11 S=1407 grid=256 rounds=3",
      "two rows on 128 members with 11 sweep waves: 256 granules, eight gathered per lane in 16 lanes per row"),
     ((3, 4, 1000000), {}, "coop RT=2 C=128 waves=8 S=977 grid=256",
@@ -169,6 +172,7 @@ def test_first_poll_pause_changes_no_bit(monkeypatch):
     overrides it, units of 256 clocks, 0 .. 31) is timing only: none, the table's and the longest give the same bits --
     on the register-window kernel and on the LDS-staged one."""
     from quantized_neural_nets_amd import StepAlgorithm as SA, _lib
+    monkeypatch.setenv("GPFQ_COOP_PIPE", "0")        # (the lock-step kernels: the pipelined ones have no such pause)
     for (N, d, m, want) in ((24, 6, 60000, "coop RT="), (300, 5, 51200, "coop RT=4 C=4 waves=13")):
         assert _lib.describe_plan(N, d, m).startswith(want), _lib.describe_plan(N, d, m)
         W, A, X = bw.synthetic_layer(N, d, m, 77 + N, first_layer=False)
