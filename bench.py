@@ -275,7 +275,8 @@ def kernel_name(desc, mode=0):
         return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
         if kv.get("pipe") == "1":                   # the pipelined kernels: four groups of RT / 4 rows; 7 sweep waves: one reducer wave
-            return "gpfq_pipe_rg%d_m%d_w8%s" % (rt // 4, mode, "s" if waves == 7 else "")
+            quad = (rt // 4) * int(kv.get("C", "0")) > 64   # four granules per lane (two rows x 128 members), one reducer wave
+            return "gpfq_pipe_rg%d_m%d_w8%s" % (rt // 4, mode, "sq" if quad else "s" if waves == 7 else "")
         if "groups" in kv:                          # one row per group (depthwise convolutions)
             return "gpfq_coop_rt1g_m%d_w12" % mode
         if rt == 1:

@@ -236,7 +236,11 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
     if (pipe_mode != 0) {
         Plan pp = *pl;
         double pcost = 0.0;
-        if (choose_pipe(Ng, S, cus, mode, &pp, &pcost, allow_rounds) && (!found || pipe_mode == 1 || pcost < best)) {
+        // (two sweep waves per member and every row on the chip at once: the lock-step step is already little more than its
+        // exchange -- measured 1.47 us per column against 1.55 pipelined on ResNet-50's layer2.{1,2,3}.conv2 -- whatever the
+        // lock-step model, which overestimates its 8-wave kernels, says)
+        if (choose_pipe(Ng, S, cus, mode, &pp, &pcost, allow_rounds) &&
+            (!found || pipe_mode == 1 || (pcost < best && !(pp.waves <= 2 && pl->rounds == 1)))) {
             *pl = pp;
             best = pcost;
             found = true;
@@ -261,9 +265,12 @@ double pipe_step_cost(int RG, int waves, int C, bool local)
 {
     const int per_simd = (waves + 3) / 4;                                  // sweep waves on the fullest SIMD
     const double sweep = (RG == 1 ? 0.13 : 0.20) * per_simd + 0.13;
-    double gather = 0.38 + (waves >= 3 ? 0.04 : 0.0) + (RG * C >= 64 ? 0.02 : 0.0);
-    if (waves == 7) gather += 0.12;                                        // (one wave for both reducer roles: + the slot tree and the store)
+    double gather = 0.38 + (waves >= 3 ? 0.04 : 0.0) + (RG * C >= 64 ? 0.02 : 0.0) + (RG * C > 64 ? 0.06 : 0.0);
+    if (waves == 7 || RG * C > 64) gather += 0.12;                                        // (one wave for both reducer roles: + the slot tree and the store)
     if (!local && gather < 0.60) gather = 0.60;
+    // (two rows x 128 members, four granules per lane, the members on four XCDs: measured 4.65 us per column and round
+    // against 3.8 for the LDS-staged four-row kernel on 64 members -- the variant exists, AUTO does not take it)
+    if (RG * C > 64 && gather < 1.15) gather = 1.15;
     return 4.0 * (sweep > gather ? sweep : gather);
 }
 
@@ -279,7 +286,8 @@ bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
         if (force_rt && RT != force_rt) continue;
         const int RG = RT / 4;
         const int64_t tiles = (Ng + RT - 1) / RT;
-        for (int C = 64 / RG; C >= 2; C >>= 1) {
+        for (int C = RG == 2 ? 128 : 64; C >= 2; C >>= 1) {                 // RG * C <= 64 granules per gather, or two rows x 128 members (four per lane)
+            if (RG * C > 64 && !(RG == 2 && C == 128)) continue;
             if (force_c && C != force_c) continue;
             if (C > S || C > cus) continue;
             const int NW = (S + C - 1) / C;
@@ -618,6 +626,17 @@ SlabKernel pipe_kernel(int RG, int mode, bool single)
     return nullptr;
 }
 
+// two rows x 128 members per gather (four granules per lane), seven sweep waves + one reducer wave
+SlabKernel pipe_kernel_quad(int mode)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return gpfq::gpfq_pipe_rg2_m1_w8sq;
+    case gpfq::MODE_HARD: return gpfq::gpfq_pipe_rg2_m2_w8sq;
+    case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_pipe_rg2_m3_w8sq;
+    default: return gpfq::gpfq_pipe_rg2_m0_w8sq;
+    }
+}
+
 // the epoch word of a pipelined granule: column + 1 in 20 bits, the launch number in 8, the publisher's XCD in 4
 bool p_d_fits_epoch(int d) { return d < (1 << 20) - 1; }
 
@@ -625,9 +644,11 @@ int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
 {
     if (!p_d_fits_epoch(sp.d)) return fail(GPFQ_ERR_UNSUPPORTED, "pipelined cooperative kernels take fewer than 2^20 columns");
     const int RT = pl.RT, RG = RT / 4;
-    const bool single = pl.waves == 7;                                 // seven sweep waves: one wave plays both reducer roles
-    SlabKernel kern = (RT == 4 || RT == 8) ? pipe_kernel(RG, mode, single) : nullptr;
-    if (!kern || pl.waves < 1 || pl.waves > 7 || RG * pl.C > 64)
+    const bool quad = RG * pl.C > 64;                                  // 256 granules per gather: four per lane (two rows x 128 members only)
+    const bool single = pl.waves == 7 || quad;                         // seven sweep waves: one wave plays both reducer roles
+    SlabKernel kern = quad ? ((RT == 8 && pl.C == 128) ? pipe_kernel_quad(mode) : nullptr)
+                           : ((RT == 4 || RT == 8) ? pipe_kernel(RG, mode, single) : nullptr);
+    if (!kern || pl.waves < 1 || pl.waves > 7)
         return fail(GPFQ_ERR_UNSUPPORTED, "internal: no pipelined cooperative kernel for this (rows, waves, members) triple");
     const int nwaves = pl.waves + (single ? 1 : 2);                    // + the publisher wave and the gatherer wave (or one for both)
     const int threads = 64 * nwaves;

@@ -95,7 +95,10 @@ __device__ __forceinline__ unsigned pipe_xcc_id() { return (__builtin_amdgcn_s_g
 // operations the compiler issues itself (the rare Q / idx flush) only make the waits longer, never shorter -- the counter
 // retires in order.  In the one-wave variant exactly one younger operation, part (a)'s store, is outstanding at the wait:
 // vmcnt(1), or the wave would sit out that store's round trip every phase.
-template <int RG, int MODE, int GV, int ROLE>
+// GPL = granules per lane of a gather (1, or 4: members 4 j .. 4 j + 3 of a row in lane j -- adjacent blocks of the slot tree,
+// added (g0 + g1) + (g2 + g3) in the lane: the first two levels of the tree over the members -- so that two rows x 128 members,
+// 256 granules, fit the 64 lanes: rows of 769 .. 896 segments, ResNet-50's 56 x 56 maps at batch 1024).
+template <int RG, int MODE, int GV, int ROLE, int GPL = 1>
 __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* segs, float* qs, float* local_flag, int NS, int lane,
                                              int tile, int c, int C, int nl, int seg_lo, int row0)
 {
@@ -117,13 +120,39 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
     // ---- gatherer state
     const kfloat* nrm = as_scalar(p.nrm2);
     float* hist = qs + RT;                               // [RT][64] values, then [RT][64] indices (as int bits)
-    const int sh = C <= 16 ? 4 : (C <= 32 ? 5 : 6);
+    static_assert(GPL == 1 || GPL == 4, "one granule per lane, or four");
+    const int lpr = C / GPL;                             // lanes per row of a gather
+    const int sh = lpr <= 16 ? 4 : (lpr <= 32 ? 5 : 6);
     const int grow = lane >> sh, member = lane & ((1 << sh) - 1);
-    const bool want = member < C && grow < RG;
+    const bool want = member < lpr && grow < RG;
     const bool lead = member == 0 && grow < RG;
     const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
     const unsigned long long unused = ~__builtin_amdgcn_ballot_w64(lead);
-    const unsigned src_off = want ? (unsigned)member * RT + (unsigned)grow : 0u;        // + gb * RG (idle lanes: member 0's granule)
+    const unsigned src_off = want ? (unsigned)(GPL * member) * RT + (unsigned)grow : 0u; // + gb * RG (idle lanes: member 0's granules)
+    // the window registers of a gather: GPL pairs from GV up; the request, the wait + read-out and the epoch test of all of them
+    auto request = [&](const unsigned long long* a) {
+        asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off sc1" :: "v"(a), "n"(GV) : "memory");
+        if constexpr (GPL == 4) {
+            asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off offset:%c2 sc1" :: "v"(a), "n"(GV + 2), "n"(8 * RT) : "memory");
+            asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off offset:%c2 sc1" :: "v"(a), "n"(GV + 4), "n"(16 * RT) : "memory");
+            asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off offset:%c2 sc1" :: "v"(a), "n"(GV + 6), "n"(24 * RT) : "memory");
+        }
+    };
+    unsigned glo[GPL], ghi[GPL];
+    auto read_out = [&]() {
+#define GPFQ_RD(i) asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c2+1]\n\ts_nop 0" : "=v"(glo[i]), "=v"(ghi[i]) : "n"(GV + 2 * i) : "memory");
+        GPFQ_RD(0)
+        if constexpr (GPL == 4) { GPFQ_RD(1) GPFQ_RD(2) GPFQ_RD(3) }
+#undef GPFQ_RD
+    };
+    auto all_arrived = [&](unsigned epoch) {
+        unsigned long long ok = __builtin_amdgcn_ballot_w64((ghi[0] & 0x0fffffffu) == epoch);
+        if constexpr (GPL == 4) {
+#pragma unroll
+            for (int i = 1; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64((ghi[i] & 0x0fffffffu) == epoch);
+        }
+        return (ok | idle) == __builtin_amdgcn_read_exec();
+    };
     bool gave_up = false;
     __builtin_amdgcn_s_setprio(3);                       // a short dependent chain among long sweeps: issue it first
     GPFQ_PSTAMP_DECL
@@ -152,7 +181,6 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
             // ---- (b) the group swept three phases ago: gather, finish the tree over the members, quantize, q into LDS
             const bool gathers = ph >= 3;
             const int pb = ph - 3, gb = pb & 3, tb = pb >> 2;
-            unsigned long long gv = 0;
             bool timed_out = false;
             float n2cur = 0.0f, in2cur = 0.0f;
             if (gathers) {
@@ -162,28 +190,25 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
                 const unsigned long long* src = xb + (unsigned)(tb & 1) * (unsigned)(C * RT) + src_off + (unsigned)(gb * RG);
                 // the first look at these granules was REQUESTED in the phase before (below): a device-scope load is a round
                 // trip of its own even when the data has long arrived
-                {
-                    unsigned lo, hi;
-                    if (published)
-                        asm volatile("s_waitcnt vmcnt(1)\n\tv_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c2+1]\n\ts_nop 0" : "=v"(lo), "=v"(hi) : "n"(GV) : "memory");
-                    else
-                        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c2+1]\n\ts_nop 0" : "=v"(lo), "=v"(hi) : "n"(GV) : "memory");
-                    gv = ((unsigned long long)hi << 32) | lo;
-                }
+                if (published) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                read_out();
                 GPFQ_PSTAMP(1)                           // the gather requested a phase ago lands
                 unsigned spins = gave_up ? p.spin_limit : 0u;
-                while ((__builtin_amdgcn_ballot_w64(((unsigned)(gv >> 32) & 0x0fffffffu) == epoch) | idle) != __builtin_amdgcn_read_exec()) {
+                while (!all_arrived(epoch)) {
                     if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
                     __builtin_amdgcn_s_sleep(1);
-                    unsigned lo, hi;
-                    asm volatile("global_load_dwordx2 v[%c3:%c3+1], %2, off sc1\n\ts_waitcnt vmcnt(0)\n\t"
-                                 "v_mov_b32 %0, v[%c3]\n\tv_mov_b32 %1, v[%c3+1]\n\ts_nop 0"
-                                 : "=v"(lo), "=v"(hi) : "v"(src), "n"(GV) : "memory");
-                    gv = ((unsigned long long)hi << 32) | lo;
+                    request(src);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    read_out();
                 }
                 if (__builtin_expect(pb == 0, 0) && p.allow_local && !timed_out) {
                     // the first gather names every member's XCD: all on this one -> the publisher may store plainly
-                    const bool elsewhere = want && ((unsigned)(gv >> 60) != my_xcc);
+                    bool elsewhere = want && ((ghi[0] >> 28) != my_xcc);
+                    if constexpr (GPL == 4) {
+#pragma unroll
+                        for (int i = 1; i < 4; ++i) elsewhere |= want && ((ghi[i] >> 28) != my_xcc);
+                    }
                     if (__builtin_amdgcn_ballot_w64(elsewhere) == 0 && lane == 0) *local_flag = __int_as_float(1);
                 }
             }
@@ -193,12 +218,13 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
             // quantizer and the barrier
             if (ph >= 2 && ph - 2 < nph) {
                 const int pn = ph - 2, gn = pn & 3, tn = pn >> 2;
-                const unsigned long long* ahead = xb + (unsigned)(tn & 1) * (unsigned)(C * RT) + src_off + (unsigned)(gn * RG);
-                asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off sc1" :: "v"(ahead), "n"(GV) : "memory");
+                request(xb + (unsigned)(tn & 1) * (unsigned)(C * RT) + src_off + (unsigned)(gn * RG));
             }
             GPFQ_PSTAMP(3)                               // the request for the next phase
             if (gathers) {
-                float v = want ? __uint_as_float((unsigned)gv) : 0.0f;
+                float v = __uint_as_float(glo[0]);
+                if constexpr (GPL == 4) v = (v + __uint_as_float(glo[1])) + (__uint_as_float(glo[2]) + __uint_as_float(glo[3]));
+                v = want ? v : 0.0f;
                 v = wave_tree16_zero_padded(v);
                 if (sh > 4) v = xor16_add(v);
                 if (sh > 5) v = xor32_add(v);
@@ -272,7 +298,7 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
 // SINGLE: one reducer wave plays both roles, leaving SEVEN sweep waves (rows whose members need a seventh segment: every
 // 1 x 1 convolution of ResNet-50 at batch 1024 has 12.3-12.5 segments per member at a power-of-two member count, i.e. 6.1-6.25
 // at twice as many); otherwise publisher and gatherer are waves of their own beside up to six sweep waves.
-template <int RG, int MODE, int WB, bool SINGLE>
+template <int RG, int MODE, int WB, bool SINGLE, int GPL = 1>
 __device__ __forceinline__ void coop_pipe_body(const SlabParams& p)
 {
     static_assert(RG == 1 || RG == 2, "groups of one row or of one interleaved pair");
@@ -308,7 +334,7 @@ __device__ __forceinline__ void coop_pipe_body(const SlabParams& p)
     if (threadIdx.x == 0) *local_flag = 0.0f;
     pipe_barrier();
     if (wave >= NS) {
-        if constexpr (SINGLE) pipe_reducer<RG, MODE, X0, 2>(p, segs, qs, local_flag, NS, lane, tile, c, C, nl, seg_lo, row0);
+        if constexpr (SINGLE) pipe_reducer<RG, MODE, X0, 2, GPL>(p, segs, qs, local_flag, NS, lane, tile, c, C, nl, seg_lo, row0);
         else if (wave == NS) pipe_reducer<RG, MODE, X0, 0>(p, segs, qs, local_flag, NS, lane, tile, c, C, nl, seg_lo, row0);
         else pipe_reducer<RG, MODE, X0, 1>(p, segs, qs, local_flag, NS, lane, tile, c, C, nl, seg_lo, row0);
         return;
@@ -453,5 +479,15 @@ GPFQ_DEFINE_PIPE(1, 0, 112, false, ) GPFQ_DEFINE_PIPE(1, 1, 112, false, ) GPFQ_D
 GPFQ_DEFINE_PIPE(2, 0, 48, false, ) GPFQ_DEFINE_PIPE(2, 1, 48, false, ) GPFQ_DEFINE_PIPE(2, 2, 48, false, ) GPFQ_DEFINE_PIPE(2, 3, 48, false, )
 GPFQ_DEFINE_PIPE(1, 0, 112, true, s) GPFQ_DEFINE_PIPE(1, 1, 112, true, s) GPFQ_DEFINE_PIPE(1, 2, 112, true, s) GPFQ_DEFINE_PIPE(1, 3, 112, true, s)
 GPFQ_DEFINE_PIPE(2, 0, 48, true, s) GPFQ_DEFINE_PIPE(2, 1, 48, true, s) GPFQ_DEFINE_PIPE(2, 2, 48, true, s) GPFQ_DEFINE_PIPE(2, 3, 48, true, s)
+
+// two rows x 128 members per gather: four granules per lane (one reducer wave, seven sweep waves)
+#define GPFQ_DEFINE_PIPE_Q(MODE)                                                                                  \
+    __global__ void __launch_bounds__(64 * 8) __attribute__((amdgpu_num_vgpr(48 / 2)))                            \
+    gpfq_pipe_rg2_m##MODE##_w8sq(const SlabParams p)                                                             \
+    {                                                                                                             \
+        asm volatile("" ::: "v255");                                                                              \
+        coop_pipe_body<2, MODE, 48, true, 4>(p);                                                                  \
+    }
+GPFQ_DEFINE_PIPE_Q(0) GPFQ_DEFINE_PIPE_Q(1) GPFQ_DEFINE_PIPE_Q(2) GPFQ_DEFINE_PIPE_Q(3)
 
 }  // namespace gpfq

@@ -38,6 +38,8 @@ CASES = [
     ((70, 12, 26624), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "4"}, "coop RT=4 C=4 waves=7 S=26 grid=72 pipe=1", "single rows with the one-wave reducer"),
     ((9, 4, 400000), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_RT": "4"}, "coop RT=4 C=64 waves=7 S=391 grid=192 pipe=1",
      "64 members of one row per gather (all 64 lanes), the last tile with one valid row"),
+    ((21, 6, 803840), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_C": "128"}, "coop RT=8 C=128 waves=7 S=785 grid=256 rounds=2 pipe=1",
+     "two rows x 128 members per gather: FOUR granules per lane, members on four XCDs (device-scope publishing); the last tile has 5 valid rows"),
     ((16, 1, 26624), {"GPFQ_COOP_PIPE": "1"}, "coop RT=8 C=16 waves=2 S=26 grid=32 pipe=1", "ONE column: the pipeline is all fill and drain"),
     ((16, 2, 26624), {"GPFQ_COOP_PIPE": "1"}, "coop RT=8 C=16 waves=2 S=26 grid=32 pipe=1", "two columns"),
     ((16, 7, 26624), {"GPFQ_COOP_PIPE": "1"}, "coop RT=8 C=16 waves=2 S=26 grid=32 pipe=1", "seven columns: the buffer rotation past one period"),
