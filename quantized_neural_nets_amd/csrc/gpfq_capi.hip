@@ -287,7 +287,7 @@ bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
         const int RG = RT / 4;
         const int64_t tiles = (Ng + RT - 1) / RT;
         for (int C = RG == 2 ? 128 : 64; C >= 2; C >>= 1) {                 // RG * C <= 64 granules per gather, or two rows x 128 members (four per lane)
-            if (RG * C > 64 && !(RG == 2 && C == 128)) continue;
+            if (RG * C > 64 && !(RG == 2 && C == 128 && force_c == 128)) continue;   // (256 granules: only when asked for, see pipe_step_cost)
             if (force_c && C != force_c) continue;
             if (C > S || C > cus) continue;
             const int NW = (S + C - 1) / C;
