@@ -536,6 +536,7 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     sp.salt = 0; sp.allow_local = 0;                // launch_pipe sets them
+    sp.prefetch_ahead = 0;                          // launch_resident decides
     return sp;
 }
 
@@ -776,7 +777,22 @@ int launch_resident(const Plan& pl, const gpfq::SlabParams& sp, int mode, int gr
     if (!k) return fail(GPFQ_ERR_UNSUPPORTED, "internal: no resident kernel for this (rows, waves) pair");
     const size_t shm = sizeof(float) * 2 * (size_t)pl.RT * (size_t)pl.S;
     dim3 grid((unsigned)((sp.Ng + pl.RT - 1) / pl.RT), (unsigned)groups, 1);
-    hipLaunchKernelGGL(k, grid, dim3((unsigned)(64 * pl.waves)), shm, st, sp);
+    // The prefetch agent (gpfq_loop_kernels.h resident_prefetch_agent): one more wave per workgroup, where the variant's wave
+    // bound has room for it, for layers whose prepared columns do not fit the 256-MB Infinity Cache (2 matrices x D x m_pad
+    // floats; ResNet-50's layer4.0.conv2 at batch 1024 is 264 MB), K columns ahead (GPFQ_RESIDENT_PREFETCH: 0 = never, a
+    // positive value forces the agent with that distance on every multi-segment resident layer that has the room)
+    gpfq::SlabParams spx = sp;
+    int nwaves = pl.waves;
+    {
+        const int want = env_int("GPFQ_RESIDENT_PREFETCH", -1);
+        const double col_bytes = 2.0 * (double)groups * (double)sp.d * (double)sp.m_pad * sizeof(float);
+        const bool room = pl.S > 1 && pl.waves + 1 <= maxw && grid.x >= 8;
+        if (room && want != 0 && (want > 0 || col_bytes > 230e6)) {
+            spx.prefetch_ahead = want > 0 ? want : 4;
+            nwaves = pl.waves + 1;
+        }
+    }
+    hipLaunchKernelGGL(k, grid, dim3((unsigned)(64 * nwaves)), shm, st, spx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ resident kernel launch");
     return GPFQ_OK;

@@ -99,6 +99,7 @@ struct SlabParams {
     float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
     unsigned spin_limit;    // cooperative kernels: 256 * (polls before an exchange gives up, host-clamped to < 2^24) + (low five bits: pause before the first poll, in units of 256 clocks, 0 .. 31)
     uint64_t seed, row_id0;
+    int prefetch_ahead; // resident kernels: columns the prefetch agent (one extra wave, active in one workgroup per XCD) runs ahead of the sweeps; 0 = no agent wave
     unsigned salt;     // pipelined kernels: 8-bit launch number carried in every granule's epoch word (a line left behind by an earlier launch never matches)
     int allow_local;   // pipelined kernels: members of a tile that find themselves on ONE XCD may publish with plain stores (the XCD's L2 is their coherence point)
 };
@@ -920,6 +921,41 @@ GPFQ_DEFINE_COOP_GROUPED(0) GPFQ_DEFINE_COOP_GROUPED(1) GPFQ_DEFINE_COOP_GROUPED
 // wave, the lane tree's total IS the dot product -- no LDS word, no barrier, no slot tree.
 // NQ (ONE only) = quarters of the segment that hold samples: m <= 256 -> 1, m <= 512 -> 2 (VGG-16's fully connected layers
 // at batch 512, AlexNet's at 32): the zero padding is neither loaded nor swept.
+// The PREFETCH AGENT of a resident workgroup (round 4): one extra wave that never sweeps.  A layer whose prepared columns
+// exceed the 256-MB Infinity Cache (ResNet-50's layer4.0.conv2 at batch 1024: 264 MB) takes every column from HBM, and a
+// column that misses holds the CU's outstanding-request slots about twice as long as one that hits: the
+// sweeps' own two steps of look-ahead do not cover it, and a third did not help (round 3).  The agent touches ONE dword of
+// every 128-byte line of columns t + K (x and a, all S segments: 64 lines per instruction) so that the lines sit in the
+// XCD's L2 when the sweep waves ask for them.  Every workgroup reads the same columns, so one agent per XCD is enough: the
+// agents of the first eight workgroups are active (workgroups b and b + 8 share an XCD under round-robin dispatch -- speed
+// only: a wrong guess prefetches into another L2 and costs nothing but the requests), the others just keep the barrier
+// count.  The loads land in a window register nobody reads; nothing waits for them (the counter saturates and throttles).
+template <int WB>
+__device__ __forceinline__ void resident_prefetch_agent(const SlabParams& p, int g, int lane)
+{
+    const bool on = blockIdx.x < 8 && blockIdx.y == 0;
+    const int K = p.prefetch_ahead;
+    const int64_t col_bytes = p.m_pad * (int64_t)sizeof(float);
+    const unsigned touched = (unsigned)p.S * 4096u;              // bytes of a column that hold samples of this layer's rows
+    const char* xb = reinterpret_cast<const char*>(p.XT + (int64_t)g * p.d * p.m_pad) + 128u * (unsigned)lane;
+    const char* ab = reinterpret_cast<const char*>(p.AT + (int64_t)g * p.d * p.m_pad) + 128u * (unsigned)lane;
+    for (int t = 0; t < p.d; ++t) {
+        const int tc = t + K;
+        if (on && tc < p.d) {
+            const char* xc = xb + tc * col_bytes;
+            const char* ac = ab + tc * col_bytes;
+            for (unsigned off = 0; off < touched; off += 8192u) {
+                if (off + 128u * (unsigned)lane < touched) {
+                    asm volatile("global_load_dword v[%c1], %0, off" :: "v"(xc + off), "n"(WB) : "memory");
+                    asm volatile("global_load_dword v[%c1], %0, off" :: "v"(ac + off), "n"(WB) : "memory");
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the step's one barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int RT, int MODE, int WB, bool ONE = false, int NQ = 4>
 __device__ __forceinline__ void resident_body(const SlabParams& p)
 {
@@ -928,9 +964,15 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
     constexpr int X0 = WB, X1 = WB + 16, X2 = WB + 32, A0 = WB + 48, A1 = WB + 64, U0 = WB + 80;
     extern __shared__ float smem[];                 // seg[2][RT][S]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int S = p.S;                              // == waves of the workgroup
+    const int S = p.S;                              // == sweep waves of the workgroup (+ the prefetch agent's wave, if launched with one)
     const int P = pow2_ceil(S);                     // slots of the canonical tree, <= 16: one DPP row per residual row
     const int row0 = blockIdx.x * RT, g = blockIdx.y;
+    if constexpr (!ONE) {
+        if (__builtin_amdgcn_readfirstlane(wave) == S) {     // launched with S + 1 waves: this one is the prefetch agent
+            resident_prefetch_agent<WB>(p, g, lane);
+            return;
+        }
+    }
     const SlotMap smap = make_slot_map(S, P, 0, 1, (lane & 15) % P, P);
     const int r16 = lane >> 4;                      // the residual row this lane serves in the slot tree
     const bool occupied = (smap.mask & 1u) && (lane & 15) < P && r16 < RT;   // other lanes contribute +0.0f

@@ -102,9 +102,10 @@ def test_the_built_isa_passes():
             cur = ln.split(":")[0]
             kernels[cur] = []
         elif cur is not None:
-            kernels[cur].append(ln)
-            if ln.strip().startswith("s_endpgm"):
+            if ln.startswith(".Lfunc_end"):              # (the whole function: role-playing waves return from the middle of it)
                 cur = None
+            else:
+                kernels[cur].append(ln)
     checked, bad, unguarded = 0, [], []
     for name, lines in kernels.items():
         kind, problems = cal.check_kernel(name, lines)
@@ -112,10 +113,19 @@ def test_the_built_isa_passes():
         bad += problems
         # every register-resident kernel (resident_* / coop_*, the LDS-staged four-row family included) keeps its
         # residual rows in a reserved window: each of them must be under the window guard, none may be skipped
-        if ("gpfq_resident_" in name or "gpfq_coop_" in name) and kind != "window":
+        if ("gpfq_resident_" in name or "gpfq_coop_" in name or "gpfq_pipe_" in name) and kind != "window":
             unguarded.append(name)
     assert checked >= 100 and bad == [] and unguarded == []
     assert sum(1 for n in kernels if "w16l" in n) == 12         # the LDS-staged family (l, lq, lh x four quantizers) was checked
+    assert sum(1 for n in kernels if "gpfq_pipe_" in n) == 20   # the pipelined family: (rg1, rg2) x (w8, w8s) + rg2 w8sq, x four quantizers
+    # ... to their END: waves that play another role (the reducer waves of a pipelined kernel, the prefetch agent of a
+    # resident one) may return from the middle of the function text, and a check that stopped at the first s_endpgm would
+    # skip the sweep loop behind it: every such kernel's checked text holds its sweeps and its last barrier
+    for name, lines in kernels.items():
+        if "gpfq_pipe_" in name or ("gpfq_resident_" in name and "_w1" not in name):
+            body = [ln.strip() for ln in lines]
+            assert any(ln.startswith(("v_pk_fma_f32", "v_fmac_f32")) for ln in body) and any(ln.startswith("s_barrier") for ln in body), name
+            assert body.index(next(ln for ln in body if ln.startswith(("v_pk_fma_f32", "v_fmac_f32")))) > 0
     assert not any(ln.strip().startswith("scratch_") for lines in kernels.values() for ln in lines)   # no kernel spills
 
 

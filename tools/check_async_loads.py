@@ -325,9 +325,12 @@ def main():
             cur = m.group(1)
             kernels[cur] = []
         elif cur is not None:
-            kernels[cur].append(ln)
-            if ln.strip().startswith("s_endpgm"):
+            # a kernel ends at its .Lfunc_end label, NOT at the first s_endpgm: kernels whose waves play different roles
+            # (the pipelined kernels' reducer waves, the resident kernels' prefetch agent) return from the middle of the text
+            if ln.startswith(".Lfunc_end"):
                 cur = None
+            else:
+                kernels[cur].append(ln)
     bad = []
     kinds = {}
     skipped = []
