@@ -536,7 +536,7 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     sp.salt = 0; sp.allow_local = 0;                // launch_pipe sets them
-    sp.prefetch_ahead = 0;                          // launch_resident decides
+    sp.prefetch_ahead = 0; sp.prefetch_lines = 1;   // launch_resident decides
     return sp;
 }
 
@@ -778,17 +778,22 @@ int launch_resident(const Plan& pl, const gpfq::SlabParams& sp, int mode, int gr
     const size_t shm = sizeof(float) * 2 * (size_t)pl.RT * (size_t)pl.S;
     dim3 grid((unsigned)((sp.Ng + pl.RT - 1) / pl.RT), (unsigned)groups, 1);
     // The prefetch agent (gpfq_loop_kernels.h resident_prefetch_agent): one more wave per workgroup, where the variant's wave
-    // bound has room for it, for layers whose prepared columns do not fit the 256-MB Infinity Cache (2 matrices x D x m_pad
-    // floats; ResNet-50's layer4.0.conv2 at batch 1024 is 264 MB), K columns ahead (GPFQ_RESIDENT_PREFETCH: 0 = never, a
-    // positive value forces the agent with that distance on every multi-segment resident layer that has the room)
+    // bound has room for it, touching the lines of column t + K so that they sit in the XCD's L2 when the sweeps ask -- the
+    // work shared by the workgroups of an XCD.  Measured per column (tools/layer_bench.py, K = 16 against none):
+    // N = 512, m = 7168 with its 264 MB of columns beyond the Infinity Cache 0.79 -> 0.66 us; N = 256, m = 7168 0.69 -> 0.54;
+    // N = 512, m = 3072 0.51 -> 0.47; N = 1024, m = 5120 (four rows) 1.07 -> 1.02; N = 2048, m = 2048 1.09 -> 1.03: never a
+    // loss, so every multi-segment resident layer of one group with the room gets one.  GPFQ_RESIDENT_PREFETCH: 0 = never,
+    // a positive value = the distance K in columns (default 16).
     gpfq::SlabParams spx = sp;
     int nwaves = pl.waves;
     {
-        const int want = env_int("GPFQ_RESIDENT_PREFETCH", -1);
-        const double col_bytes = 2.0 * (double)groups * (double)sp.d * (double)sp.m_pad * sizeof(float);
-        const bool room = pl.S > 1 && pl.waves + 1 <= maxw && grid.x >= 8;
-        if (room && want != 0 && (want > 0 || col_bytes > 230e6)) {
-            spx.prefetch_ahead = want > 0 ? want : 4;
+        const int want = env_int("GPFQ_RESIDENT_PREFETCH", 16);
+        const int per_xcd = (int)((grid.x + 7) / 8);                       // workgroups that share an XCD's L2 (round-robin dispatch)
+        const int lp = per_xcd >= 32 ? 1 : (per_xcd >= 16 ? 2 : (per_xcd >= 8 ? 4 : 0));
+        const bool room = pl.S > 1 && pl.waves + 1 <= maxw && groups == 1 && lp > 0 && 2 * pl.S * lp <= 64;
+        if (room && want > 0) {
+            spx.prefetch_ahead = want;
+            spx.prefetch_lines = lp;
             nwaves = pl.waves + 1;
         }
     }

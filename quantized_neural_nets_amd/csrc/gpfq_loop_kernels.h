@@ -99,6 +99,7 @@ struct SlabParams {
     float msq_thr;     // 0.5 - (K + 4) * 2^-18: how far from the middle of [n, n + 1) that path trusts its floor
     unsigned spin_limit;    // cooperative kernels: 256 * (polls before an exchange gives up, host-clamped to < 2^24) + (low five bits: pause before the first poll, in units of 256 clocks, 0 .. 31)
     uint64_t seed, row_id0;
+    int prefetch_lines; // resident kernels: lines of every segment one workgroup's agent touches (32 / workgroups per XCD, at least 1)
     int prefetch_ahead; // resident kernels: columns the prefetch agent (one extra wave, active in one workgroup per XCD) runs ahead of the sweeps; 0 = no agent wave
     unsigned salt;     // pipelined kernels: 8-bit launch number carried in every granule's epoch word (a line left behind by an earlier launch never matches)
     int allow_local;   // pipelined kernels: members of a tile that find themselves on ONE XCD may publish with plain stores (the XCD's L2 is their coherence point)
@@ -924,33 +925,34 @@ GPFQ_DEFINE_COOP_GROUPED(0) GPFQ_DEFINE_COOP_GROUPED(1) GPFQ_DEFINE_COOP_GROUPED
 // The PREFETCH AGENT of a resident workgroup (round 4): one extra wave that never sweeps.  A layer whose prepared columns
 // exceed the 256-MB Infinity Cache (ResNet-50's layer4.0.conv2 at batch 1024: 264 MB) takes every column from HBM, and a
 // column that misses holds the CU's outstanding-request slots about twice as long as one that hits: the
-// sweeps' own two steps of look-ahead do not cover it, and a third did not help (round 3).  The agent touches ONE dword of
-// every 128-byte line of columns t + K (x and a, all S segments: 64 lines per instruction) so that the lines sit in the
-// XCD's L2 when the sweep waves ask for them.  Every workgroup reads the same columns, so one agent per XCD is enough: the
-// agents of the first eight workgroups are active (workgroups b and b + 8 share an XCD under round-robin dispatch -- speed
-// only: a wrong guess prefetches into another L2 and costs nothing but the requests), the others just keep the barrier
-// count.  The loads land in a window register nobody reads; nothing waits for them (the counter saturates and throttles).
+// sweeps' own two steps of look-ahead do not cover it, and a third did not help (round 3).  The agents touch ONE dword of
+// every 128-byte line of columns t + K (x and a) so that the lines sit in the XCD's L2 when the sweep waves ask for them.
+// Every workgroup reads the same columns, so the work is SHARED by the workgroups of an XCD (b and b + 8 share one under
+// round-robin dispatch -- speed only: a wrong guess prefetches into another L2): workgroup j of its XCD (j = (b >> 3) & 31)
+// touches line j of every segment, x in lanes 0 .. S-1 and a in lanes S .. 2S-1: ONE load instruction per step with 2 S
+// active lanes (fewer workgroups per XCD: LP = 2 or 4 lines of every segment each).  (First version: the agents of eight workgroups touched everything, 64 different lines per instruction, 14
+// instructions per step -- an uncoalesced load occupies the CU's address unit for as long as 64 separate ones, those eight
+// workgroups fell behind and the layer went from 0.77 to 0.98 us per column.)  The loads land in a window register nobody
+// reads; nothing waits for them.
 template <int WB>
 __device__ __forceinline__ void resident_prefetch_agent(const SlabParams& p, int g, int lane)
 {
-    const bool on = blockIdx.x < 8 && blockIdx.y == 0;
     const int K = p.prefetch_ahead;
+    const int S = p.S;
+    const int LP = p.prefetch_lines;                             // lines of a segment this workgroup touches (1 with 32+ workgroups per XCD)
+    const int W = 32 / LP;                                       // workgroups of an XCD that share a segment's 32 lines
     const int64_t col_bytes = p.m_pad * (int64_t)sizeof(float);
-    const unsigned touched = (unsigned)p.S * 4096u;              // bytes of a column that hold samples of this layer's rows
-    const char* xb = reinterpret_cast<const char*>(p.XT + (int64_t)g * p.d * p.m_pad) + 128u * (unsigned)lane;
-    const char* ab = reinterpret_cast<const char*>(p.AT + (int64_t)g * p.d * p.m_pad) + 128u * (unsigned)lane;
+    const unsigned j = (blockIdx.x >> 3) % (unsigned)W;          // this workgroup's share
+    const int per_matrix = S * LP;
+    const bool mine = lane < 2 * per_matrix;
+    const int rem = lane < per_matrix ? lane : lane - per_matrix;
+    const unsigned line = j + (unsigned)(rem % LP) * (unsigned)W;
+    const char* base = reinterpret_cast<const char*>((lane < per_matrix ? p.XT : p.AT) + (int64_t)g * p.d * p.m_pad) +
+                       (mine ? (unsigned)(rem / LP) * 4096u + 128u * line : 0u);
     for (int t = 0; t < p.d; ++t) {
         const int tc = t + K;
-        if (on && tc < p.d) {
-            const char* xc = xb + tc * col_bytes;
-            const char* ac = ab + tc * col_bytes;
-            for (unsigned off = 0; off < touched; off += 8192u) {
-                if (off + 128u * (unsigned)lane < touched) {
-                    asm volatile("global_load_dword v[%c1], %0, off" :: "v"(xc + off), "n"(WB) : "memory");
-                    asm volatile("global_load_dword v[%c1], %0, off" :: "v"(ac + off), "n"(WB) : "memory");
-                }
-            }
-        }
+        if (mine && tc < p.d)
+            asm volatile("global_load_dword v[%c1], %0, off" :: "v"(base + tc * col_bytes), "n"(WB) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the step's one barrier
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
