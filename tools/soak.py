@@ -26,7 +26,7 @@ def main():
     t0 = time.time()
     bad = 0
     for ci in range(ncases):
-        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise", "chip_wide"])
+        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise", "chip_wide", "pipe", "pipe"])
         groups = 1
         if fam == "wave":                           # one-segment rows: the resident kernel's one-wave variant, 1 / 2 / 4 rows per wave
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
@@ -53,6 +53,14 @@ def main():
                 N, m = int(rng.integers(5, 40)), int(rng.integers(786433, 830000))
             else:
                 N, m = int(rng.integers(1, 5)), int(rng.integers(2700000, 3300000))
+        elif fam == "pipe":                         # the pipelined cooperative kernels (round 4): four groups of one row or of a pair,
+            N, m = int(rng.integers(4, 300)), int(rng.integers(16385, 260000))   # any member count they take, both reducer arrangements
+            os.environ["GPFQ_COOP_PIPE"] = "1"
+            os.environ["GPFQ_COOP_RT"] = str(int(rng.choice([4, 8])))
+            if rng.integers(0, 3) == 0:
+                os.environ["GPFQ_PIPE_LOCAL"] = "0"  # device-scope publishing throughout
+            if rng.integers(0, 2):
+                os.environ["GPFQ_COOP_C"] = str(int(rng.choice([2, 4, 8, 16, 32, 64])))
         elif fam == "stream":
             N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
         elif fam == "depthwise":                    # one long row per group: the cooperative one-row kernel's grouped variant
@@ -61,7 +69,7 @@ def main():
         else:
             groups = int(rng.choice([2, 3, 4]))
             N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
-        d = int(rng.integers(1, 5 if fam == "chip_wide" else 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam == "coop_rows" else 40))
+        d = int(rng.integers(1, 5 if fam == "chip_wide" else 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam in ("coop_rows", "pipe") else 40))
         bits = int(rng.choice([2, 3, 4]))
         reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
         plan = 1 if fam == "stream" else 0
@@ -79,10 +87,10 @@ def main():
         o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
         full = _lib.describe_plan(N, d, m, groups, plan)
         desc = (full.split(" S=")[0] if full.startswith("coop") else full.split()[0]) + (
-            "+groups" if "groups=" in full else "+rounds" if "rounds=" in full else "")
+            "+groups" if "groups=" in full else "+rounds" if "rounds=" in full else "") + ("+pipe" if "pipe=1" in full else "")
         kinds[desc] = kinds.get(desc, 0) + 1
-        os.environ.pop("GPFQ_COOP_RT", None)
-        os.environ.pop("GPFQ_COOP_C", None)
+        for k in ("GPFQ_COOP_RT", "GPFQ_COOP_C", "GPFQ_COOP_PIPE", "GPFQ_PIPE_LOCAL"):
+            os.environ.pop(k, None)
         ok = (np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
               and np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))
               and np.array_equal(r["U"].cpu().numpy(), o["U"])
