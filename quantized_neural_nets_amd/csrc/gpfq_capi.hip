@@ -638,6 +638,21 @@ SlabKernel pipe_kernel_quad(int mode)
     }
 }
 
+// Launch of a grid whose workgroups wait for each other.  Default: a plain launch behind the occupancy check of the caller
+// (the grid is sized to be co-resident on an otherwise idle chip; every spin is bounded and a timeout is reported).
+// GPFQ_COOP_LAUNCH_API=1: hipLaunchCooperativeKernel, with which the RUNTIME refuses a grid that cannot be co-resident
+// (hipErrorCooperativeLaunchTooLarge) instead of letting it spin to its bound -- measured in round 4 (profiles/NOTES.md):
+// adopted only if it costs no more than 2 us per launch.
+hipError_t launch_waiting_grid(SlabKernel kern, dim3 grid, dim3 block, size_t shm, hipStream_t st, gpfq::SlabParams& sp)
+{
+    if (env_int("GPFQ_COOP_LAUNCH_API", 0)) {
+        void* args[] = {&sp};
+        return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), grid, block, args, (unsigned)shm, st);
+    }
+    hipLaunchKernelGGL(kern, grid, block, shm, st, sp);
+    return hipGetLastError();
+}
+
 // the epoch word of a pipelined granule: column + 1 in 20 bits, the launch number in 8, the publisher's XCD in 4
 bool p_d_fits_epoch(int d) { return d < (1 << 20) - 1; }
 
@@ -671,8 +686,7 @@ int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     static std::atomic<unsigned> launch_number{0};
     spx.salt = launch_number.fetch_add(1) & 255u;
     spx.allow_local = env_int("GPFQ_PIPE_LOCAL", 1) && p_d_fits_epoch(sp.d);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
-    e = hipGetLastError();
+    e = launch_waiting_grid(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
     if (e != hipSuccess) return hip_fail(e, "GPFQ pipelined cooperative kernel launch");
     return GPFQ_OK;
 }
@@ -722,8 +736,7 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_COOP_POLL_DELAY", first_poll_pause(RT, pl.C, pl.waves, lds)) & 31u);
     const bool depth1 = (RT == 4 && maxw == 12) || (RT == 2 && maxw == 16);
     spx.xcd_tiles = env_int("GPFQ_COOP_XCD_TILES", (!depth1 && pl.S <= 128) ? 1 : 0);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
-    e = hipGetLastError();
+    e = launch_waiting_grid(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
     if (e != hipSuccess) return hip_fail(e, "GPFQ cooperative kernel launch");
     return GPFQ_OK;
 }

@@ -26,7 +26,8 @@ def _run(W, A, X, m, step):
     ((200, 30, 5000), "200 workgroups: 25 per XCD, two lines of every segment each"),
     ((100, 30, 5000), "100 workgroups: 13 per XCD, four lines of every segment each"),
     ((40, 30, 5000), "40 workgroups: fewer than eight per XCD -- no agent"),
-    ((300, 12, 15000), "15 sweep waves + the agent: the 16-wave variant full"),
+    ((40, 12, 15000), "15 sweep waves + the agent: the 16-wave variant full (40 workgroups: four lines each would need 120 lanes -- no agent)"),
+    ((256, 12, 11000), "11 sweep waves + the agent in the 12-wave variant"),
     ((300, 3, 7168), "three columns: the agent's distance exceeds the layer"),
 ])
 def test_prefetch_agent_changes_no_bit(oracle_mod, monkeypatch, shape, why):
@@ -41,5 +42,5 @@ def test_prefetch_agent_changes_no_bit(oracle_mod, monkeypatch, shape, why):
     for k in ("0", "1", "5"):
         monkeypatch.setenv("GPFQ_RESIDENT_PREFETCH", k)
         r = _run(W, A, X, m, step)
-        assert torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"]) and torch.equal(r["Q"], ref["Q"]) and \\
-            torch.equal(r["usq_seg"], ref["usq_seg"]), k
+        assert torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"]) and torch.equal(r["Q"], ref["Q"]), k
+        assert torch.equal(r["usq_seg"], ref["usq_seg"]), k
