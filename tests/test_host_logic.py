@@ -64,25 +64,27 @@ def test_plan_selection(lib):
     assert lib.describe_plan(256, 2304, 7168).startswith("resident")
     assert "S=7" in lib.describe_plan(256, 2304, 7168)
     assert lib.describe_plan(64, 576, 93184, 1, lib.PLAN_STREAM).startswith("stream")
-    assert lib.describe_plan(64, 576, 93184).startswith("coop RT=2 C=8 waves=12")
-    assert lib.describe_plan(128, 1152, 93184).startswith("coop RT=4 C=8 waves=12")
-    assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=2 C=4 waves=7")
-    assert lib.describe_plan(256, 2304, 26624).startswith("coop RT=4 C=4 waves=7")
+    # the pipelined cooperative kernels (round 4) where they are modelled -- and were measured -- faster than the lock-step ones
+    assert lib.describe_plan(64, 576, 93184).startswith("coop RT=4 C=16 waves=6 S=91 grid=256 pipe=1")
+    assert lib.describe_plan(128, 1152, 93184).startswith("coop RT=8 C=16 waves=6 S=91 grid=256 pipe=1")
+    assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=2 C=4 waves=7 S=26 grid=256 d=")     # two sweep waves per member: lock-step stays
+    assert lib.describe_plan(256, 2304, 26624).startswith("coop RT=8 C=8 waves=4 S=26 grid=256 pipe=1")
     assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=16 waves=6")        # an 8-GPU shard of 64 rows
     assert lib.describe_plan(32, 2304, 26624).startswith("coop RT=1 C=8 waves=4")       # an 8-GPU shard of 256 rows
-    assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=4 C=2 waves=7")      # long rows, more rows than CUs
+    assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=8 C=4 waves=4 S=13 grid=256 pipe=1")   # long rows, more rows than CUs
     assert lib.describe_plan(64, 9, 30000, 64).startswith("coop RT=1 C=4 waves=8 S=30 grid=256 rounds=1 groups=64")   # depthwise, long rows: one row per group
     assert lib.describe_plan(96, 9, 370688, 96).startswith("coop RT=1 C=32 waves=12 S=362 grid=256 rounds=12 groups=96")
     assert lib.describe_plan(64, 9, 30000, 32).startswith("stream")                     # two rows per group: not the depthwise case
     # long rows, more of them than the chip holds: cooperative in rounds (one co-resident launch per block of rows)
     # (four rows x 13 sweep waves: the variant that stages its columns through LDS)
-    assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=4 C=4 waves=13 S=50 grid=256 rounds=8")
-    assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=16 waves=13 S=197 grid=256 rounds=16")
+    # (eight rows per tile, seven sweep waves + ONE reducer wave for both roles: the pipelined `_w8s` variant)
+    assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=8 C=8 waves=7 S=50 grid=256 rounds=8 pipe=1")
+    assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=8 C=32 waves=7 S=197 grid=256 rounds=16 pipe=1")
     assert lib.describe_plan(256, 64, 803840).startswith("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16")    # 256 granules
     assert lib.describe_plan(256, 512, 13312).startswith("resident RT=1 waves=13")      # <= 16 segments, one round: whole rows, no exchange
     assert lib.describe_plan(16, 32, 3212288).startswith("coop RT=4 C=256 waves=13 S=3137 grid=256 rounds=4")    # four rows on the whole chip (1024 granules)
     assert lib.describe_plan(2, 32, 3212288).startswith("coop RT=2 C=256 waves=13 S=3137 grid=256 d=32")           # two rows: the 512-granule kernel
-    assert lib.describe_plan(2048, 512, 13312).startswith("coop RT=4 C=2 waves=7 S=13 grid=256 rounds=4")          # cooperative rounds against resident rounds
+    assert lib.describe_plan(2048, 512, 13312).startswith("coop RT=8 C=2 waves=7 S=13 grid=256 rounds=2 pipe=1")   # cooperative rounds against resident rounds
     assert lib.describe_plan(1, 32, 3212288).startswith("coop RT=1 C=256 waves=13 S=3137 grid=256 d=32")         # one row on the whole chip
     assert lib.describe_plan(4, 8, 4194304).startswith("stream")                        # 4096 segments: beyond 256 members x 15
     assert lib.describe_plan(1000, 2048, 1024).startswith("resident")
@@ -92,6 +94,23 @@ def test_plan_selection(lib):
         assert desc.startswith("stream") and " C=" not in desc, desc
     with pytest.raises(lib.GpfqError):
         lib.describe_plan(8, 8, 4_200_000)
+
+
+def test_plan_selection_lock_step_family(lib, monkeypatch):
+    """GPFQ_COOP_PIPE=0: the cooperative choices of rounds 1-3 (the lock-step kernels stay in the library and stay the choice
+    for one or two rows per tile, one row per group, 13 sweep waves and 256+ granules)."""
+    monkeypatch.setenv("GPFQ_COOP_PIPE", "0")
+    assert lib.describe_plan(64, 576, 93184).startswith("coop RT=2 C=8 waves=12")
+    assert lib.describe_plan(128, 1152, 93184).startswith("coop RT=4 C=8 waves=12")
+    assert lib.describe_plan(256, 2304, 26624).startswith("coop RT=4 C=4 waves=7")
+    assert lib.describe_plan(512, 4608, 13312).startswith("coop RT=4 C=2 waves=7")
+    assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=4 C=4 waves=13 S=50 grid=256 rounds=8")
+    assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=16 waves=13 S=197 grid=256 rounds=16")
+    assert lib.describe_plan(2048, 512, 13312).startswith("coop RT=4 C=2 waves=7 S=13 grid=256 rounds=4")
+    monkeypatch.setenv("GPFQ_COOP_PIPE", "1")        # forced: also where AUTO would not take it
+    assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=8 C=16 waves=2 S=26 grid=256 pipe=1")
+    monkeypatch.setenv("GPFQ_COOP_C", "128")         # 256 granules per gather: only when asked for
+    assert lib.describe_plan(21, 6, 803840).startswith("coop RT=8 C=128 waves=7 S=785 grid=256 rounds=2 pipe=1")
 
 
 def test_partition_covers_every_neuron_once():
@@ -256,7 +275,10 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
                     key=lambda f: [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(f))])[-1]
     real = json.load(open(newest))
     assert real["source_sha256"] == digest, "%s was collected on other kernel sources: re-collect (tools/profile_bench.sh)" % newest
-    assert any("gpfq_resident_rt2_m0_w8" in k for k in real["kernels"]) and any("gpfq_coop_rt4_m0_w12" in k for k in real["kernels"])
+    # (the headline's kernels since round 4: the resident ones, the pipelined cooperative ones, and the lock-step two-row kernel
+    # that keeps layer2.{1,2,3}.conv2)
+    assert any("gpfq_resident_rt2_m0_w8" in k for k in real["kernels"]) and any("gpfq_pipe_rg2_m0_w8" in k for k in real["kernels"])
+    assert any("gpfq_coop_rt2_m0_w8" in k for k in real["kernels"])
     # ... and so does the counter summary behind roofline_issue / the measured roofline_l2
     newest_c = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters.json")),
                       key=lambda f: [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(f))])[-1]
