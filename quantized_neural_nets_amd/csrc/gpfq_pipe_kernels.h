@@ -130,12 +130,15 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
     const unsigned long long unused = ~__builtin_amdgcn_ballot_w64(lead);
     const unsigned src_off = want ? (unsigned)(GPL * member) * RT + (unsigned)grow : 0u; // + gb * RG (idle lanes: member 0's granules)
     // the window registers of a gather: GPL pairs from GV up; the request, the wait + read-out and the epoch test of all of them
-    auto request = [&](const unsigned long long* a) {
-        asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off sc1" :: "v"(a), "n"(GV) : "memory");
+    // (scalar base + per-lane 32-bit byte offset: the base -- tile, parity of the step, group -- is computed by the scalar unit,
+    // the lane part never changes; as per-lane 64-bit pointers every request cost four 64-bit vector additions)
+    const unsigned lane_bytes = 8u * src_off;
+    auto request = [&](const unsigned long long* base) {
+        asm volatile("global_load_dwordx2 v[%c2:%c2+1], %0, %1 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV) : "memory");
         if constexpr (GPL == 4) {
-            asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off offset:%c2 sc1" :: "v"(a), "n"(GV + 2), "n"(8 * RT) : "memory");
-            asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off offset:%c2 sc1" :: "v"(a), "n"(GV + 4), "n"(16 * RT) : "memory");
-            asm volatile("global_load_dwordx2 v[%c1:%c1+1], %0, off offset:%c2 sc1" :: "v"(a), "n"(GV + 6), "n"(24 * RT) : "memory");
+            asm volatile("global_load_dwordx2 v[%c2:%c2+1], %0, %1 offset:%c3 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 2), "n"(8 * RT) : "memory");
+            asm volatile("global_load_dwordx2 v[%c2:%c2+1], %0, %1 offset:%c3 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 4), "n"(16 * RT) : "memory");
+            asm volatile("global_load_dwordx2 v[%c2:%c2+1], %0, %1 offset:%c3 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 6), "n"(24 * RT) : "memory");
         }
     };
     unsigned glo[GPL], ghi[GPL];
@@ -156,16 +159,21 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
     bool gave_up = false;
     __builtin_amdgcn_s_setprio(3);                       // a short dependent chain among long sweeps: issue it first
     GPFQ_PSTAMP_DECL
-    for (int ph = 0; ph < nph + 3; ++ph) {
+    // one phase.  STEADY: 4 <= ph < 4 d -- every part of the phase runs (a publish, a gather, a request) and the locality flag
+    // has been decided: no range tests, no flag read; the seven phases of fill and drain take the general form
+    auto phase = [&](auto steady_, const int ph) {
+        constexpr bool STEADY = decltype(steady_)::value;
         GPFQ_PSTAMP(0)                                   // the barrier
         bool published = false;
         if constexpr (PUB) {
             // ---- (a) the group swept in the phase before: this member's block of the slot tree, published
-            published = ph >= 1 && ph <= nph;
+            published = STEADY || (ph >= 1 && ph <= nph);
             if (published) {
                 const int pa = ph - 1, ga = pa & 3, ta = pa >> 2;
                 const float val = segs[ga * RG * NS + seg_word];
-                if (!local && ph >= 4) local = __builtin_amdgcn_readfirstlane(__float_as_int(*local_flag)) != 0;
+                if constexpr (!STEADY) {
+                    if (!local && ph >= 4) local = __builtin_amdgcn_readfirstlane(__float_as_int(*local_flag)) != 0;
+                }
                 const float v = wave_tree16_zero_padded(mine ? val : 0.0f);
                 unsigned long long* dst = xb + (unsigned)(ta & 1) * (unsigned)(C * RT) + pub_off + (unsigned)(ga * RG);
                 const unsigned long long granule = ((unsigned long long)(tag | (my_xcc << 28) | ((unsigned)ta + 1u)) << 32) |
@@ -179,7 +187,7 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
         }
         if constexpr (GAT) {
             // ---- (b) the group swept three phases ago: gather, finish the tree over the members, quantize, q into LDS
-            const bool gathers = ph >= 3;
+            const bool gathers = STEADY || ph >= 3;
             const int pb = ph - 3, gb = pb & 3, tb = pb >> 2;
             bool timed_out = false;
             float n2cur = 0.0f, in2cur = 0.0f;
@@ -187,7 +195,7 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
                 const unsigned epoch = tag | ((unsigned)tb + 1u);
                 n2cur = sload(nrm, 8u * (unsigned)tb);
                 in2cur = sload(nrm, 8u * (unsigned)tb + 4u);
-                const unsigned long long* src = xb + (unsigned)(tb & 1) * (unsigned)(C * RT) + src_off + (unsigned)(gb * RG);
+                const unsigned long long* src = xb + (unsigned)(tb & 1) * (unsigned)(C * RT) + (unsigned)(gb * RG);    // (uniform: + the lane's offset in the load)
                 // the first look at these granules was REQUESTED in the phase before (below): a device-scope load is a round
                 // trip of its own even when the data has long arrived
                 if (published) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -202,7 +210,7 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     read_out();
                 }
-                if (__builtin_expect(pb == 0, 0) && p.allow_local && !timed_out) {
+                if (!STEADY && pb == 0 && p.allow_local && !timed_out) {
                     // the first gather names every member's XCD: all on this one -> the publisher may store plainly
                     bool elsewhere = want && ((ghi[0] >> 28) != my_xcc);
                     if constexpr (GPL == 4) {
@@ -216,9 +224,9 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
             // ---- the gather of the NEXT phase, requested as soon as the window pair is free again: the group swept two
             // phases ago, published by every member at the top of its phase ph - 1; the load travels under this phase's
             // quantizer and the barrier
-            if (ph >= 2 && ph - 2 < nph) {
+            if (STEADY || (ph >= 2 && ph - 2 < nph)) {
                 const int pn = ph - 2, gn = pn & 3, tn = pn >> 2;
-                request(xb + (unsigned)(tn & 1) * (unsigned)(C * RT) + src_off + (unsigned)(gn * RG));
+                request(xb + (unsigned)(tn & 1) * (unsigned)(C * RT) + (unsigned)(gn * RG));
             }
             GPFQ_PSTAMP(3)                               // the request for the next phase
             if (gathers) {
@@ -283,6 +291,14 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
             GPFQ_PSTAMP(4)                               // tree over the members, quantizer, q into LDS, rare flush
         }
         pipe_barrier();
+    };
+    {
+        int ph = 0;
+        const int fill = nph < 5 ? nph + 3 : 5;          // phases 0 .. 4: the flag is read in phase 4 (written in phase 3)
+        for (; ph < fill; ++ph) phase(std::false_type{}, ph);
+        if (PUB && !local && ph >= 5) local = __builtin_amdgcn_readfirstlane(__float_as_int(*local_flag)) != 0;
+        for (; ph < nph; ++ph) phase(std::true_type{}, ph);
+        for (; ph < nph + 3; ++ph) phase(std::false_type{}, ph);
     }
 #ifdef GPFQ_STAMPS
     if (blockIdx.x == 0 && lane == 0 && p.status) {
