@@ -297,7 +297,9 @@ bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
             const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
             if (rounds > 1 && !allow_rounds) continue;
             if ((size_t)tiles_round * 2 * C * RT * sizeof(unsigned long long) > kScratchStatusOffset) continue;
-            const bool local = C <= cus / 8 && (tiles_round & 7) == 0 && env_int("GPFQ_PIPE_LOCAL", 1);
+            // (a tile's members on one XCD: launch_pipe pads the grid to a multiple of eight tiles where the chip has the room)
+            const bool local = C <= cus / 8 && ((tiles_round + 7) & ~(int64_t)7) * C <= cus && env_int("GPFQ_PIPE_LOCAL", 1) &&
+                               env_int("GPFQ_COOP_XCD_TILES", 1);
             const double cost = (double)rounds * pipe_step_cost(RG, NW, C, local);
             if (!found || cost < best - 1e-9) {
                 found = true;
@@ -669,11 +671,15 @@ int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     const int nwaves = pl.waves + (single ? 1 : 2);                    // + the publisher wave and the gatherer wave (or one for both)
     const int threads = 64 * nwaves;
     const size_t shm = sizeof(float) * ((size_t)RT * pl.waves + RT + 2 * (size_t)RT * 64 + 4);   // (+ the locality flag)
-    const int nblocks = pl.tiles * pl.C;
+    const int cus = device_cu_count();
+    // XCD placement (speed; the kernel verifies it before relying on it): the grid is padded to a multiple of eight tiles
+    // where the chip holds that many workgroups, so that tile k's members can sit on XCD k mod 8 whatever the tile count
+    const int tiles_padded = (pl.tiles + 7) & ~7;
+    const bool place = env_int("GPFQ_COOP_XCD_TILES", 1) && tiles_padded * pl.C <= cus;
+    const int nblocks = (place ? tiles_padded : pl.tiles) * pl.C;
     int nb = 0;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, shm);
     if (e != hipSuccess) return hip_fail(e, "occupancy query");
-    const int cus = device_cu_count();
     if (nb < 1 || nblocks > cus) return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
     size_t xbytes = (size_t)pl.tiles * 2 * pl.C * RT * sizeof(unsigned long long);
     xbytes = (xbytes + 15) & ~(size_t)15;
@@ -682,7 +688,7 @@ int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
     gpfq::SlabParams spx = sp;
     spx.spin_limit = sp.spin_limit & ~255u;                            // (no pause before a gather: the granules are two phases old)
-    spx.xcd_tiles = env_int("GPFQ_COOP_XCD_TILES", 1);
+    spx.xcd_tiles = place ? 1 : 0;
     static std::atomic<unsigned> launch_number{0};
     spx.salt = launch_number.fetch_add(1) & 255u;
     spx.allow_local = env_int("GPFQ_PIPE_LOCAL", 1) && p_d_fits_epoch(sp.d);

@@ -328,10 +328,14 @@ __device__ __forceinline__ void coop_pipe_body(const SlabParams& p)
     const int P = pow2_ceil(S);
     if (*static_cast<volatile const int*>(p.status) != 0) return;      // (a layer in rounds stops at the first timed-out launch)
     int tile, c;
-    if (p.xcd_tiles && (p.tiles & 7) == 0) {        // members of a row tile on one XCD (speed only)
+    if (p.xcd_tiles) {
+        // The members of a row tile on one XCD (workgroups b and b + 8 share one under round-robin dispatch; the kernel
+        // verifies it before it relies on it, pipe_reducer).  The host pads the grid to a multiple of eight tiles where the
+        // chip has the room: the workgroups of the tiles that do not exist leave at once -- nobody waits for them.
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         tile = (j / C) * 8 + xcd;
         c = j % C;
+        if (tile >= p.tiles) return;
     } else {
         tile = blockIdx.x / C;
         c = blockIdx.x % C;

@@ -64,10 +64,15 @@ def _worker(rank, world, port, case_name, out_dir):
         step = float(fx["step"])
         ctx = qd.enable()
         assert qd.active() is ctx and ctx.world == world
+        # the hook bench.py hangs its events on: called around the layer-end all_gather of the index shards, in pairs
+        tags = []
+        ctx.event_hook = tags.append
         Wt, At, Xt = torch.from_numpy(W), torch.from_numpy(A), torch.from_numpy(X)
         Q, idx, U_loc, usq_seg, rows = qd.quantize_sharded(ctx, Wt, At, At.shape[1], Xt, Xt.shape[1], groups, dg, step, K,
                                                            mode, float(np.float32(case["lamb"])), torch.int8,
                                                            _oracle_run_rows(step, K, mode, case["lamb"], m, dg))
+        assert tags == ["collective_begin", "collective_end"], tags      # ONE collective of indices per layer
+        ctx.event_hook = None
         met = qd.sharded_error_metrics(ctx, Wt, At, usq_seg.double().sum(1), groups, rows, U_loc)
         # stochastic quantizer: the Philox keys are the GLOBAL row numbers, so the sharded draw equals the unsharded one
         # (this is what used to break for 1 < groups < world)

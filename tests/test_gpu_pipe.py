@@ -30,7 +30,10 @@ CASES = [
     ((256, 10, 26624), {}, "coop RT=8 C=8 waves=4 S=26 grid=256 pipe=1", "four sweep waves"),
     ((128, 10, 26624), {"GPFQ_COOP_PIPE": "1"}, "coop RT=8 C=16 waves=2 S=26 grid=256 pipe=1", "two sweep waves, members of 1 and 2 segments"),
     ((24, 20, 26624), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_C": "8"}, "coop RT=8 C=8 waves=4 S=26 grid=24 pipe=1",
-     "3 tiles: not a multiple of the XCDs, members spread -- device-scope publishing throughout"),
+     "3 tiles: the grid is padded to 8 tiles so that each tile's members share an XCD; the workgroups of tiles 3..7 leave at once"),
+    ((24, 20, 26624), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_C": "8", "GPFQ_COOP_XCD_TILES": "0"}, "coop RT=8 C=8 waves=4 S=26 grid=24 pipe=1",
+     "the same without placement: members spread over the XCDs -- the first gather finds it, device-scope publishing throughout"),
+    ((112, 9, 51200), {}, "coop RT=8 C=16 waves=4 S=50 grid=224 pipe=1", "14 tiles padded to 16 (EfficientNet-B1's 112-channel project convs)"),
     ((300, 24, 51200), {}, "coop RT=8 C=8 waves=7 S=50 grid=256 rounds=2 pipe=1",
      "SEVEN sweep waves: one wave for both reducer roles (vmcnt(1) behind its own store); the last round partial"),
     ((2048, 6, 13312), {}, "coop RT=8 C=2 waves=7 S=13 grid=256 rounds=2 pipe=1", "two members per tile, the one-wave reducer"),

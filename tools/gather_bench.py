@@ -27,3 +27,16 @@ for (B, C, H, k, pad) in [(1024, 64, 56, 3, 1), (1024, 128, 28, 3, 1), (1024, 25
     ms = e0.elapsed_time(e1) / 10
     out_bytes = T.numel() * 4
     print("B=%d C=%d H=%d k=%d: m=%d d=%d  %.3f ms  out %.1f MB -> %.0f GB/s written" % (B, C, H, k, m, C*k*k, ms, out_bytes/1e6, out_bytes/ms/1e6))
+    if os.environ.get("GATHER_SORTED"):
+        # upper bound of what reading the patches of a 64-column block in position order could give (round 4 experiment: the
+        # columns come out in sorted order here, which the product could only undo with a lane permutation per value)
+        blk = torch.arange(m, device=dev) // 64
+        order = torch.argsort(blk * (1 << 40) + sel, stable=True)
+        sel_sorted = sel[order].contiguous()
+        sel_keep, sel = sel, sel_sorted
+        run(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10): run()
+        e1.record(); torch.cuda.synchronize()
+        print("    patches sorted by position inside every 64-column block: %.3f ms" % (e0.elapsed_time(e1) / 10))
+        sel = sel_keep
