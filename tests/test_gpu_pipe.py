@@ -114,3 +114,19 @@ def test_classic_lock_step_kernels_stay_selectable(monkeypatch):
     monkeypatch.setenv("GPFQ_COOP_PIPE", "0")
     assert _lib.describe_plan(64, 576, 93184).startswith("coop RT=2 C=8 waves=12 S=91 grid=256 d=")
     assert _lib.describe_plan(1024, 256, 51200).startswith("coop RT=4 C=4 waves=13 S=50 grid=256 rounds=4 d=")
+
+
+def test_runtime_enforced_coresidency_launch_gives_the_same_bits(monkeypatch):
+    """GPFQ_COOP_LAUNCH_API=1: grids whose workgroups wait for each other go through hipLaunchCooperativeKernel (the runtime
+    refuses a grid that cannot be co-resident instead of letting it spin) -- same kernels, same outputs, on the pipelined
+    and on the lock-step family."""
+    from quantized_neural_nets_amd import _lib
+    for (N, d, m, want) in ((64, 9, 93184, "pipe=1"), (128, 9, 26624, "coop RT=2 C=4")):
+        assert want in _lib.describe_plan(N, d, m)
+        W, A, X = bw.synthetic_layer(N, d, m, 8 + N, first_layer=False)
+        step = bw.layer_step(W)
+        monkeypatch.delenv("GPFQ_COOP_LAUNCH_API", raising=False)
+        ref = _run(W, A, X, m, 0, step=step)
+        monkeypatch.setenv("GPFQ_COOP_LAUNCH_API", "1")
+        r = _run(W, A, X, m, 0, step=step)
+        assert r["timeouts"] == [] and torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"])
