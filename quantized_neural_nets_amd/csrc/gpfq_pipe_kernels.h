@@ -210,6 +210,10 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     read_out();
                 }
+                // a limit of zero polls: no exchange may be waited for at all, and none counts as answered -- the first gather
+                // reports a timeout whether its granules had arrived or not (with XCD-local publishing they always have: the
+                // tests that force the timeout path need it to be deterministic)
+                if (!STEADY && pb == 0 && (p.spin_limit >> 8) == 0u) timed_out = true;
                 if (!STEADY && pb == 0 && p.allow_local && !timed_out) {
                     // the first gather names every member's XCD: all on this one -> the publisher may store plainly
                     bool elsewhere = want && ((ghi[0] >> 28) != my_xcc);
