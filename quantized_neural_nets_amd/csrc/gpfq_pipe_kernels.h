@@ -141,6 +141,17 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
             asm volatile("global_load_dwordx2 v[%c2:%c2+1], %0, %1 offset:%c3 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 6), "n"(24 * RT) : "memory");
         }
     };
+    // ... and the re-poll's: its base may come straight out of a spill slot (v_readlane, a VALU write of the SGPR pair), which an
+    // asm VMEM instruction may read only five wait states later -- the compiler pads its own loads, not ours
+    // (ONE statement with the first load: operands are reloaded in front of a statement, never inside it)
+    auto request_again = [&](const unsigned long long* base) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[%c2:%c2+1], %0, %1 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV) : "memory");
+        if constexpr (GPL == 4) {
+            asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[%c2:%c2+1], %0, %1 offset:%c3 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 2), "n"(8 * RT) : "memory");
+            asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[%c2:%c2+1], %0, %1 offset:%c3 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 4), "n"(16 * RT) : "memory");
+            asm volatile("s_nop 4\n\tglobal_load_dwordx2 v[%c2:%c2+1], %0, %1 offset:%c3 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 6), "n"(24 * RT) : "memory");
+        }
+    };
     unsigned glo[GPL], ghi[GPL];
     auto read_out = [&]() {
 #define GPFQ_RD(i) asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c2+1]\n\ts_nop 0" : "=v"(glo[i]), "=v"(ghi[i]) : "n"(GV + 2 * i) : "memory");
@@ -157,6 +168,12 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
         return (ok | idle) == __builtin_amdgcn_read_exec();
     };
     bool gave_up = false;
+    // the column norm of a gather is requested ONE PHASE AHEAD (scalar loads return out of order: every wait on their counter
+    // is a wait for all of them, so a request made at the top of the phase it is used in puts a whole scalar-cache round trip --
+    // a trip to L2 every eighth column -- in front of the quantizer; requested behind the previous phase's first use, it has a
+    // whole phase to land, and the barrier's wait on the counter has seen it home)
+    float n2nx = 0.0f, in2nx = 0.0f;
+    if constexpr (GAT) { n2nx = sload(nrm, 0u); in2nx = sload(nrm, 4u); }
     __builtin_amdgcn_s_setprio(3);                       // a short dependent chain among long sweeps: issue it first
     GPFQ_PSTAMP_DECL
     // one phase.  STEADY: 4 <= ph < 4 d -- every part of the phase runs (a publish, a gather, a request) and the locality flag
@@ -193,8 +210,17 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
             float n2cur = 0.0f, in2cur = 0.0f;
             if (gathers) {
                 const unsigned epoch = tag | ((unsigned)tb + 1u);
-                n2cur = sload(nrm, 8u * (unsigned)tb);
-                in2cur = sload(nrm, 8u * (unsigned)tb + 4u);
+                n2cur = n2nx;
+                in2cur = in2nx;
+                asm volatile("" : "+s"(n2cur), "+s"(in2cur));           // (the use that waits for last phase's request, long home)
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    int tn = (ph - 2) >> 2;                              // the column of the NEXT phase's gather
+                    if constexpr (!STEADY) tn = tn < p.d ? tn : p.d - 1;
+                    n2nx = sload(nrm, 8u * (unsigned)tn);
+                    in2nx = sload(nrm, 8u * (unsigned)tn + 4u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 const unsigned long long* src = xb + (unsigned)(tb & 1) * (unsigned)(C * RT) + (unsigned)(gb * RG);    // (uniform: + the lane's offset in the load)
                 // the first look at these granules was REQUESTED in the phase before (below): a device-scope load is a round
                 // trip of its own even when the data has long arrived
@@ -202,13 +228,16 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 read_out();
                 GPFQ_PSTAMP(1)                           // the gather requested a phase ago lands
-                unsigned spins = gave_up ? p.spin_limit : 0u;
-                while (!all_arrived(epoch)) {
-                    if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    request(src);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    read_out();
+                // (the answered first look falls straight through: as a `while` the compiler's layout put three taken branches on it)
+                if (__builtin_expect(!all_arrived(epoch), 0)) {
+                    unsigned spins = gave_up ? p.spin_limit : 0u;
+                    do {
+                        if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        request_again(src);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        read_out();
+                    } while (!all_arrived(epoch));
                 }
                 // a limit of zero polls: no exchange may be waited for at all, and none counts as answered -- the first gather
                 // reports a timeout whether its granules had arrived or not (with XCD-local publishing they always have: the
