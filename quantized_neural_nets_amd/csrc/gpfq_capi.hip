@@ -742,10 +742,6 @@ int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_COOP_POLL_DELAY", first_poll_pause(RT, pl.C, pl.waves, lds)) & 31u);
     const bool depth1 = (RT == 4 && maxw == 12) || (RT == 2 && maxw == 16);
     spx.xcd_tiles = env_int("GPFQ_COOP_XCD_TILES", (!depth1 && pl.S <= 128) ? 1 : 0);
-    // XCD-local publishing (gpfq_loop_kernels.h reducer_section): offered wherever the placement above puts a tile's members
-    // on one XCD; the kernel switches only after step 0's granules have shown that they are (the epoch word carries the
-    // publisher's XCD in its top four bits, so d must stay below 2^28).  GPFQ_COOP_LOCAL=0: device-scope stores throughout.
-    spx.allow_local = (spx.xcd_tiles && (pl.tiles & 7) == 0 && sp.d < (1 << 28) && env_int("GPFQ_COOP_LOCAL", 1)) ? 1 : 0;
     e = launch_waiting_grid(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
     if (e != hipSuccess) return hip_fail(e, "GPFQ cooperative kernel launch");
     return GPFQ_OK;

@@ -130,24 +130,11 @@ __device__ __forceinline__ float quantize_mode(const SlabParams& p, float s, uin
 // the lane), so that up to 256 members -- a whole chip for one row of up to 4096 segments -- fit the 64 lanes.  With two
 // rows (256 members x 2 rows = 512 granules) a lane gathers EIGHT members, 8j .. 8j+7, three levels in the lane.
 // GOVR (QUAD only) overrides the members per lane: 16 for FOUR rows on 256 members (1024 granules, four batches of four).
-// XCD-LOCAL PUBLISHING (LOCALOK variants; the pipelined kernels' protocol, gpfq_pipe_kernels.h).  A device-scope store is a
-// write-through to the fabric, and a member on the same XCD reads the line back from memory: 0.67 us per exchange on an idle
-// chip against 0.36 us with a plain store, which stays in that XCD's L2, where device-scope loads -- they bypass only the
-// vector L1 -- find it (profiles/r03_xchg_probe.txt).  Members on OTHER XCDs never see a plain store, so locality is
-// ESTABLISHED, not assumed: the epoch word of every granule names its publisher's XCD in its top four bits (HW_REG_XCC_ID + 1;
-// the epoch itself is t + 1 < 2^28, the host checks d); step 0 is published device-scope; step 0's gather compares the
-// members' XCDs with this workgroup's own, and if they all match the later steps publish plainly.  Every member of a tile
-// sees the same set of XCDs, so a tile switches as a whole; one member elsewhere and it never does.
-// `rs` = the reducer wave's state across steps: bit 0 an exchange of this launch has timed out (the later ones give up at
-// their first unanswered poll), bit 1 the tile publishes plainly.
-__device__ __forceinline__ unsigned coop_xcc_id() { return (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u) + 1u; }
-
-template <int RT, int MODE, bool FAST, bool ABORTWORD, bool QUAD = false, int GOVR = 0, bool LOCALOK = false>
+template <int RT, int MODE, bool FAST, bool ABORTWORD, bool QUAD = false, int GOVR = 0>
 __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float* seg, float* qs, const SlotMap smap,
                                         int NW, int nl, int lane, int tile, int c, int C, int par,
-                                        int t, float n2cur, float in2cur, int row0, int64_t grow0, int seg_lo, unsigned& rs)
+                                        int t, float n2cur, float in2cur, int row0, int64_t grow0, int seg_lo, bool gave_up)
 {
-    const bool gave_up = (rs & 1u) != 0u;
     // this workgroup's block of the slot tree for all RT rows at once: lane = 16 * row + slot
     float v;
     {
@@ -169,15 +156,12 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
     const int member = lane & ((1 << sh) - 1);
     {
         const unsigned epoch = (unsigned)t + 1u;
-        const unsigned my_xcc = LOCALOK ? coop_xcc_id() : 0u;       // (variants that never publish plainly: the epoch word stays t + 1)
-        constexpr unsigned kEpochMask = LOCALOK ? 0x0fffffffu : 0xffffffffu;
         // (32-bit offset arithmetic: the exchange area is 96 KiB; as size_t this was four 64-bit multiplies per step)
         unsigned long long* xb_ = p.xbuf + (unsigned)(tile * 2 + par) * (unsigned)(C * RT);
-        if ((lane & 15) == 0 && (lane >> 4) < RT) {
-            const unsigned long long granule = ((unsigned long long)(epoch | (my_xcc << 28)) << 32) | (unsigned long long)__float_as_uint(v);
-            if (LOCALOK && (rs & 2u)) __hip_atomic_store(xb_ + (size_t)c * RT + (lane >> 4), granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_store(xb_ + (size_t)c * RT + (lane >> 4), granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if ((lane & 15) == 0 && (lane >> 4) < RT)
+            __hip_atomic_store(xb_ + (size_t)c * RT + (lane >> 4),
+                               ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool want = member < per_row && gr_ < RT;
         const unsigned long long* src = xb_ + (want ? (size_t)(QUAD ? G * member : (wide ? 2 * member : member)) * RT + gr_ : 0);
         unsigned long long gv = 0, gw = 0;
@@ -221,7 +205,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
                     for (int i = 0; i < 4; ++i)
                         g[i] = __hip_atomic_load(src + (4 * b + i) * RT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (idle lanes: granules 0 .. G-1, in bounds: C >= G)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64(((unsigned)(g[i] >> 32) & kEpochMask) == epoch);
+                    for (int i = 0; i < 4; ++i) ok &= __builtin_amdgcn_ballot_w64((unsigned)(g[i] >> 32) == epoch);
                     vq[b] = (__uint_as_float((unsigned)g[0]) + __uint_as_float((unsigned)g[1])) +
                             (__uint_as_float((unsigned)g[2]) + __uint_as_float((unsigned)g[3]));
                     if constexpr (G >= 8) __builtin_amdgcn_sched_barrier(0);
@@ -237,7 +221,7 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         } else if (!wide) {
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((__builtin_amdgcn_ballot_w64(((unsigned)(gv >> 32) & kEpochMask) == epoch) | idle) == __builtin_amdgcn_read_exec()) break;
+                if ((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) | idle) == __builtin_amdgcn_read_exec()) break;
                 if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -247,20 +231,12 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
             for (;;) {
                 gv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 gw = __hip_atomic_load(src1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (((__builtin_amdgcn_ballot_w64(((unsigned)(gv >> 32) & kEpochMask) == epoch) &
-                      __builtin_amdgcn_ballot_w64(((unsigned)(gw >> 32) & kEpochMask) == epoch)) | idle) == __builtin_amdgcn_read_exec()) break;
+                if (((__builtin_amdgcn_ballot_w64((unsigned)(gv >> 32) == epoch) &
+                      __builtin_amdgcn_ballot_w64((unsigned)(gw >> 32) == epoch)) | idle) == __builtin_amdgcn_read_exec()) break;
                 if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             v = want ? __uint_as_float((unsigned)gv) + __uint_as_float((unsigned)gw) : 0.0f;
-        }
-        if constexpr (LOCALOK && !QUAD) {
-            // step 0's granules name every member's XCD: all on this one -> the later steps publish plainly
-            if (__builtin_expect(t == 0, 0) && p.allow_local && !timed_out) {
-                bool elsewhere = want && ((unsigned)(gv >> 60) != my_xcc);
-                if (wide) elsewhere |= want && ((unsigned)(gw >> 60) != my_xcc);
-                if (__builtin_amdgcn_ballot_w64(elsewhere) == 0) rs |= 2u;
-            }
         }
         // upper levels of the slot tree over the members of each row
         v = wave_tree16_zero_padded(v);
@@ -333,7 +309,6 @@ __device__ __forceinline__ bool reducer_section(const SlabParams& p, const float
         atomicExch(p.status, 1);
         p.status[1] = t; p.status[2] = tile; p.status[3] = c;
     }
-    if (timed_out) rs |= 1u;
     return timed_out;
 }
 
@@ -517,7 +492,7 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
 #endif
     int t = 0;
     constexpr bool ABORTWORD = (RT == 4 && DEPTH == 1);
-    unsigned rs = 0;                                // reducer wave: bit 0 an exchange of this launch has timed out, bit 1 plain publishing (reducer_section)
+    bool gave_up = false;                           // reducer wave: an exchange of this launch has timed out
     bool dead = false;                              // ABORTWORD only
     // Column requests in the exchange window (below) only when the reducer is a wave of its own: where wave 0 doubles as
     // the reducer (12 sweep waves) the window requests of the other eleven waves sit in front of its polls and the
@@ -585,13 +560,12 @@ __device__ __forceinline__ void coop_body(const SlabParams& p)
         const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
         if (wave == rwave) {
             GPFQ_STAMP(4)
-            if constexpr (ABORTWORD) {
-                unsigned none = 0;                   // (no state across steps in this variant)
+            if constexpr (ABORTWORD)
                 reducer_section<RT, MODE, false, true>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t, n2cur, in2cur, row0,
-                                                       grow0, seg_lo, none);
-            } else
-                reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD, 0, !QUAD>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
-                                                                                               n2cur, in2cur, row0, grow0, seg_lo, rs);
+                                                       grow0, seg_lo, false);
+            else
+                gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
+                                                                                    n2cur, in2cur, row0, grow0, seg_lo, gave_up);
             GPFQ_STAMP(5)
         } else if (trickle && active) {
             // The exchange window: the sweep waves idle here for ~2 000 cycles while the reducer's granules travel.  Their
@@ -758,7 +732,7 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
         dma(cols + 2048, ag);
     }
     int t = 0;
-    unsigned rs = 0;                                // (reducer_section: bit 0 = an exchange has timed out)
+    bool gave_up = false;
     for (;;) {
         const int par = t & 1;
         const bool more = t + 1 < p.d;
@@ -820,8 +794,8 @@ __device__ __forceinline__ void coop_lds_body(const SlabParams& p)
         for (int r = 0; r < RT; ++r) wn[r] = sload(wrow[r], 4u * (unsigned)tn);
         const float n2n = sload(nrm, 8u * (unsigned)tn), in2n = sload(nrm, 8u * (unsigned)tn + 4u);
         if (wave == rwave)
-            reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD, GOVR>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
-                                                                           n2cur, in2cur, row0, grow0, seg_lo, rs);
+            gave_up |= reducer_section<RT, MODE, MODE == MODE_MSQ, false, QUAD, GOVR>(p, seg, qs, smap, NW, nl, lane, tile, c, C, par, t,
+                                                                                      n2cur, in2cur, row0, grow0, seg_lo, gave_up);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int r = 0; r < RT; ++r) qprev[r] = qs[par * (RT + 1) + r];

@@ -168,12 +168,6 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
         return (ok | idle) == __builtin_amdgcn_read_exec();
     };
     bool gave_up = false;
-    // the column norm of a gather is requested ONE PHASE AHEAD (scalar loads return out of order: every wait on their counter
-    // is a wait for all of them, so a request made at the top of the phase it is used in puts a whole scalar-cache round trip --
-    // a trip to L2 every eighth column -- in front of the quantizer; requested behind the previous phase's first use, it has a
-    // whole phase to land, and the barrier's wait on the counter has seen it home)
-    float n2nx = 0.0f, in2nx = 0.0f;
-    if constexpr (GAT) { n2nx = sload(nrm, 0u); in2nx = sload(nrm, 4u); }
     __builtin_amdgcn_s_setprio(3);                       // a short dependent chain among long sweeps: issue it first
     GPFQ_PSTAMP_DECL
     // one phase.  STEADY: 4 <= ph < 4 d -- every part of the phase runs (a publish, a gather, a request) and the locality flag
@@ -210,17 +204,8 @@ __device__ __forceinline__ void pipe_reducer(const SlabParams& p, const float* s
             float n2cur = 0.0f, in2cur = 0.0f;
             if (gathers) {
                 const unsigned epoch = tag | ((unsigned)tb + 1u);
-                n2cur = n2nx;
-                in2cur = in2nx;
-                asm volatile("" : "+s"(n2cur), "+s"(in2cur));           // (the use that waits for last phase's request, long home)
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    int tn = (ph - 2) >> 2;                              // the column of the NEXT phase's gather
-                    if constexpr (!STEADY) tn = tn < p.d ? tn : p.d - 1;
-                    n2nx = sload(nrm, 8u * (unsigned)tn);
-                    in2nx = sload(nrm, 8u * (unsigned)tn + 4u);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                n2cur = sload(nrm, 8u * (unsigned)tb);
+                in2cur = sload(nrm, 8u * (unsigned)tb + 4u);
                 const unsigned long long* src = xb + (unsigned)(tb & 1) * (unsigned)(C * RT) + (unsigned)(gb * RG);    // (uniform: + the lane's offset in the load)
                 // the first look at these granules was REQUESTED in the phase before (below): a device-scope load is a round
                 // trip of its own even when the data has long arrived

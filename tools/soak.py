@@ -26,7 +26,7 @@ def main():
     t0 = time.time()
     bad = 0
     for ci in range(ncases):
-        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise", "chip_wide", "pipe", "pipe"])
+        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise", "chip_wide", "pipe", "pipe", "lock"])
         groups = 1
         if fam == "wave":                           # one-segment rows: the resident kernel's one-wave variant, 1 / 2 / 4 rows per wave
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
@@ -61,6 +61,13 @@ def main():
                 os.environ["GPFQ_PIPE_LOCAL"] = "0"  # device-scope publishing throughout
             if rng.integers(0, 2):
                 os.environ["GPFQ_COOP_C"] = str(int(rng.choice([2, 4, 8, 16, 32, 64])))
+        elif fam == "lock":                         # the lock-step kernels where AUTO would pipeline: tile counts that are multiples
+            rt = int(rng.choice([1, 2, 4]))         # of eight (members of a tile placed on one XCD), and some that are not
+            N = rt * 8 * int(rng.integers(1, 5)) - (int(rng.integers(0, rt * 8)) if rng.integers(0, 4) == 0 else 0)
+            m = int(rng.integers(16385, 120000))
+            os.environ["GPFQ_COOP_PIPE"] = "0"
+            os.environ["GPFQ_COOP_RT"] = str(rt)
+            os.environ["GPFQ_COOP_C"] = str(int(rng.choice([2, 4, 8, 16, 32])))
         elif fam == "stream":
             N, m = int(rng.integers(1, 12)), int(rng.integers(16385, 90000))
         elif fam == "depthwise":                    # one long row per group: the cooperative one-row kernel's grouped variant
@@ -69,7 +76,7 @@ def main():
         else:
             groups = int(rng.choice([2, 3, 4]))
             N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
-        d = int(rng.integers(1, 5 if fam == "chip_wide" else 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam in ("coop_rows", "pipe") else 40))
+        d = int(rng.integers(1, 5 if fam == "chip_wide" else 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam in ("coop_rows", "pipe", "lock") else 40))
         bits = int(rng.choice([2, 3, 4]))
         reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
         plan = 1 if fam == "stream" else 0
