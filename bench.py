@@ -738,10 +738,12 @@ def main():
     fam = {}
     table = []
     prep_ms_total = loop_ms_total = coll_ms_total = 0.0
+    prep_bytes_total = 0.0                           # the transposing preparation: both (m, D) matrices read, both (D, m_pad) written
     for name, N, dg, m, groups in (l[:5] for l in layers):
         rec = per_layer.get(name)
         if not rec:
             continue
+        prep_bytes_total += 2.0 * 4.0 * dg * groups * (m + _lib.lib.gpfq_padded_m(m))
         Nl = N
         if world > 1 or args.emulate_world > 1:
             kind_, chunk = qdist.partition(N, groups, max(world, args.emulate_world))
@@ -867,6 +869,15 @@ def main():
             "roofline": roofline,
             "roofline_l2": roofline_l2,
             "roofline_issue": roofline_issue,
+            # the one HBM-bound part of a step: the column preparation (every rank repeats it in full)
+            "roofline_prep": (None if args.capture or prep_ms_total <= 0 else
+                              {"bound": "hbm", "kernel": "gpfq_transpose_norm_kernel (+ gpfq_colnorm_finish_kernel)",
+                               "achieved": round(prep_bytes_total / (prep_ms_total * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(prep_bytes_total / (prep_ms_total * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "bytes_per_step": int(prep_bytes_total), "ms_per_step": round(prep_ms_total, 3),
+                               "definition": "bytes the preparation must move (A and X read once as (m, D) fp32, AT and XT written once as "
+                                             "(D, m_pad) fp32) / its time in this run (events on the launch stream, all layers of a step) "
+                                             "/ 8 TB/s; a plain device copy of such sizes reaches 5.3 TB/s = 0.66 (tools/scratch/copy_rate.py)"}),
             "output_check": output_check,
         }
         failed = bool(output_check and output_check["mismatches"])
