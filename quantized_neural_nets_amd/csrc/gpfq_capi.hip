@@ -1055,7 +1055,13 @@ int gpfq_prepare_columns_ws_f32(const float* A, int64_t lda, const float* X, int
     if (TC != 32 && TC != 64) TC = (flat || wg64 >= 16 * (int64_t)cus) ? 64 : 32;
     if (flat) TC = 64;
     const int ntile = (int)((D + TC - 1) / TC);
-    const int G = ntile < 512 / TC ? ntile : 512 / TC;      // column tiles side by side: 2 KB of every input row
+    // Column tiles side by side (workgroups that run together read neighbouring pieces of the same input rows): up to 2 KB of
+    // every row, in groups of EQUAL size.  With groups of 512 / TC tiles and a ragged last one -- D = 576 is 9 tiles of 64:
+    // 8 + 1 -- the last group is a tail of S workgroups per matrix with no neighbours and an emptying chip: 3.84 TB/s on
+    // 93 184 x 576, 4.78 with 5 + 4 (tools/prep_bench.py; 4.29 -> 4.77 at D = 1 152, 4.34 -> 4.77 at 26 624 x 2 304).
+    const int gmax = 512 / TC;
+    const int ngr = (ntile + gmax - 1) / gmax;
+    const int G = (ntile + ngr - 1) / ngr;
     const int64_t ngroups = (ntile + G - 1) / G;
     const int64_t nblocks = ngroups * S * 2 * G;
     if (nblocks > 0x7fffffffLL) return fail(GPFQ_ERR_UNSUPPORTED, "too many column tiles");

@@ -35,8 +35,12 @@ for name, N, dg, m, g in (l[:5] for l in layers):
     st = _lib.current_stream_ptr(dev)
     by = 2 * (m * D + mp * D) * 4
     row = "%-24s m=%8d D=%5d %7.1f MB:" % (name, m, D, by / 1e6)
-    for tag, env in (("two-pass", {"GPFQ_NO_FUSED_PREP": "1"}), ("tc64", {"GPFQ_PREP_TC": "64"}), ("tc32", {"GPFQ_PREP_TC": "32"}), ("auto", {})):
-        for k in ("GPFQ_NO_FUSED_PREP", "GPFQ_PREP_TC"):
+    configs = (("two-pass", {"GPFQ_NO_FUSED_PREP": "1"}), ("tc64", {"GPFQ_PREP_TC": "64"}), ("tc32", {"GPFQ_PREP_TC": "32"}), ("auto", {}))
+    if os.environ.get("PREP_CONFIGS"):              # "tag:K=V,K=V;tag:..." replaces the default set; outputs are compared with the first one's
+        configs = tuple((c.split(":")[0], dict(kv.split("=") for kv in c.split(":")[1].split(",") if kv)) for c in os.environ["PREP_CONFIGS"].split(";"))
+    ref = None
+    for tag, env in configs:
+        for k in [k for k in os.environ if k.startswith("GPFQ_") and k != "GPFQ_LIB_OVERRIDE"]:
             os.environ.pop(k, None)
         os.environ.update(env)
         def run():
@@ -50,7 +54,12 @@ for name, N, dg, m, g in (l[:5] for l in layers):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         tot[tag] = tot.get(tag, 0.0) + ms
-        row += "  %s %.3f ms %.2f TB/s" % (tag, ms, by / ms / 1e9)
+        same = ""
+        if ref is None:
+            ref = (AT.clone(), XT.clone(), nrm.clone())
+        elif not (torch.equal(ref[0], AT) and torch.equal(ref[1], XT) and torch.equal(ref[2], nrm)):
+            same = " DIFFERENT"
+        row += "  %s %.3f ms %.2f TB/s%s" % (tag, ms, by / ms / 1e9, same)
     print(row, flush=True)
-    del A, X, AT, XT
+    del A, X, AT, XT, ref
 print("total ms:", {k: round(v, 3) for k, v in tot.items()})
