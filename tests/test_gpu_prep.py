@@ -47,6 +47,9 @@ CASES = [
     (4096, 128, 0, 1, "base misaligned by one element: guarded loads"),
     (3333, 40, 0, 2, "flat shape but misaligned base: tiled guarded loads"),
     (66000, 100, 12, 0, "65 segments, strided, ragged"),
+    (2048, 1100, 0, 0, "35 tiles of 32 columns in three groups of 12 (one slot of the last group empty), ragged last tile"),
+    (3000, 2310, 2, 0, "73 tiles in five groups of 15 (two empty slots), strided, guarded loads"),
+    (66000, 2100, 0, 0, "enough workgroups for 64-column tiles: 33 tiles in five groups of 7 (two empty slots)"),
     (1100000, 8, 0, 0, "1075 segments: 32 slots per lane in the slot tree"),
     (3212288, 4, 0, 0, "3137 segments (EfficientNet-B1's 112 x 112 maps at batch 1024)"),
 ]
