@@ -1,4 +1,6 @@
 #!/bin/bash
+# (how to make the base library: check out the commit to compare against, `make -C quantized_neural_nets_amd/csrc`, copy
+#  csrc/build/libgpfq_hip.so to csrc/stamps/libgpfq_hip_base.so -- git-ignored, travels to the GPU box -- and come back)
 # same-box A/B inside bench.py: the library of the last profile set (stamps/libgpfq_hip_base.so) against the working tree's
 BASE=$PWD/quantized_neural_nets_amd/csrc/stamps/libgpfq_hip_base.so
 run() { # label, workload args...

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (how to make the base library: check out the commit to compare against, `make -C quantized_neural_nets_amd/csrc`, copy
+#  csrc/build/libgpfq_hip.so to csrc/stamps/libgpfq_hip_base.so -- git-ignored, travels to the GPU box -- and come back)
 # same-box A/B inside the headline bench: lock-step XCD-local publishing off / on / off / on, per-layer loop times of layer2.{1,2,3}.conv2
 for i in 1 2; do
   for L in 0 1; do

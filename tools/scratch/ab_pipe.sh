@@ -1,4 +1,6 @@
 #!/bin/bash
+# (how to make the base library: check out the commit to compare against, `make -C quantized_neural_nets_amd/csrc`, copy
+#  csrc/build/libgpfq_hip.so to csrc/stamps/libgpfq_hip_base.so -- git-ignored, travels to the GPU box -- and come back)
 # same-box A/B of the pipelined / lock-step kernels: the library of HEAD (stamps/libgpfq_hip_base.so) against the working tree's
 BASE=$PWD/quantized_neural_nets_amd/csrc/stamps/libgpfq_hip_base.so
 SH="256,2304,26624 128,1152,26624 128,1152,93184 64,576,93184 1024,512,51200"
