@@ -266,6 +266,12 @@ double pipe_step_cost(int RG, int waves, int C, bool local)
     const int per_simd = (waves + 3) / 4;                                  // sweep waves on the fullest SIMD
     const double sweep = (RG == 1 ? 0.13 : 0.20) * per_simd + 0.13;
     double gather = 0.38 + (waves >= 3 ? 0.04 : 0.0) + (RG * C >= 64 ? 0.02 : 0.0) + (RG * C > 64 ? 0.06 : 0.0);
+    // (single rows with at most one sweep wave per SIMD: the sweep waves are at the barrier early and the gatherer's phase is the
+    // shortest measured -- N = 128, 26 segments, four rows x 8 members: 1.36 us per column against 1.43 as eight rows x 16 members
+    // and 1.46 on the lock-step two-row kernel)
+    // (up to 16 members, one DPP row per gather: with 32 the same layout loses to the lock-step one-row kernel, 1.64 against
+    // 1.52-1.62 on 8 and 16 rows of 91 segments)
+    if (RG == 1 && waves <= 4 && C <= 16) gather = 0.34;
     if (waves == 7 || RG * C > 64) gather += 0.12;                                        // (one wave for both reducer roles: + the slot tree and the store)
     if (!local && gather < 0.60) gather = 0.60;
     // (two rows x 128 members, four granules per lane, the members on four XCDs: measured 4.65 us per column and round

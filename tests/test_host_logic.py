@@ -67,7 +67,8 @@ def test_plan_selection(lib):
     # the pipelined cooperative kernels (round 4) where they are modelled -- and were measured -- faster than the lock-step ones
     assert lib.describe_plan(64, 576, 93184).startswith("coop RT=4 C=16 waves=6 S=91 grid=256 pipe=1")
     assert lib.describe_plan(128, 1152, 93184).startswith("coop RT=8 C=16 waves=6 S=91 grid=256 pipe=1")
-    assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=2 C=4 waves=7 S=26 grid=256 d=")     # two sweep waves per member: lock-step stays
+    assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=4 C=8 waves=4 S=26 grid=256 pipe=1")  # four single rows x 8 members (1.23-1.36 us per column; lock-step two rows x 4 members 1.46)
+    assert lib.describe_plan(64, 576, 23296).startswith("coop RT=2 C=8 waves=3 S=23 grid=256 d=")        # the pipelined choice would have two sweep waves per member: lock-step stays
     assert lib.describe_plan(256, 2304, 26624).startswith("coop RT=8 C=8 waves=4 S=26 grid=256 pipe=1")
     assert lib.describe_plan(8, 576, 93184).startswith("coop RT=1 C=16 waves=6")        # an 8-GPU shard of 64 rows
     assert lib.describe_plan(32, 2304, 26624).startswith("coop RT=1 C=8 waves=4")       # an 8-GPU shard of 256 rows
@@ -107,8 +108,12 @@ def test_plan_selection_lock_step_family(lib, monkeypatch):
     assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=4 C=4 waves=13 S=50 grid=256 rounds=8")
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=16 waves=13 S=197 grid=256 rounds=16")
     assert lib.describe_plan(2048, 512, 13312).startswith("coop RT=4 C=2 waves=7 S=13 grid=256 rounds=4")
+    assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=2 C=4 waves=7 S=26 grid=256 d=")
     monkeypatch.setenv("GPFQ_COOP_PIPE", "1")        # forced: also where AUTO would not take it
+    assert lib.describe_plan(64, 576, 23296).startswith("coop RT=4 C=16 waves=2 S=23 grid=256 pipe=1")
+    monkeypatch.setenv("GPFQ_COOP_RT", "8")
     assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=8 C=16 waves=2 S=26 grid=256 pipe=1")
+    monkeypatch.delenv("GPFQ_COOP_RT")
     monkeypatch.setenv("GPFQ_COOP_C", "128")         # 256 granules per gather: only when asked for
     assert lib.describe_plan(21, 6, 803840).startswith("coop RT=8 C=128 waves=7 S=785 grid=256 rounds=2 pipe=1")
 
