@@ -280,10 +280,10 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
                     key=lambda f: [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(f))])[-1]
     real = json.load(open(newest))
     assert real["source_sha256"] == digest, "%s was collected on other kernel sources: re-collect (tools/profile_bench.sh)" % newest
-    # (the headline's kernels since round 4: the resident ones, the pipelined cooperative ones, and the lock-step two-row kernel
-    # that keeps layer2.{1,2,3}.conv2)
+    # (the headline's kernels since round 4: the resident ones and the pipelined cooperative ones -- layer2.{1,2,3}.conv2 moved
+    # from the lock-step two-row kernel to four single rows x 8 members late in the round)
     assert any("gpfq_resident_rt2_m0_w8" in k for k in real["kernels"]) and any("gpfq_pipe_rg2_m0_w8" in k for k in real["kernels"])
-    assert any("gpfq_coop_rt2_m0_w8" in k for k in real["kernels"])
+    assert any("gpfq_pipe_rg1_m0_w8" in k for k in real["kernels"]) and any("gpfq_resident_rt1_m0_w8" in k for k in real["kernels"])
     # ... and so does the counter summary behind roofline_issue / the measured roofline_l2
     newest_c = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters.json")),
                       key=lambda f: [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", os.path.basename(f))])[-1]
