@@ -91,6 +91,20 @@ int gpfq_read_status(void* scratch, int* status_host4, void* stream);
 int gpfq_last_launch_used_exchange(void);
 
 /*
+ * Diagnostics of the cooperative plans (no reference counterpart: the reference has no workgroups that wait for each other).
+ * gpfq_spin_limit_word: the bound the kernels count their polls against, 256 * min(GPFQ_COOP_SPIN_LIMIT, 2^24 - 2) -- the
+ *   kernels test `(spins += 256) > word + pause` (pause < 32), so the word must leave the 32-bit counter room to EXCEED it.
+ * gpfq_coop_launch_api_active: 1 if the next cooperative grid on the current device is launched through
+ *   hipLaunchCooperativeKernel (the runtime then refuses a grid that cannot be co-resident instead of letting it spin to its
+ *   bound): always with GPFQ_COOP_LAUNCH_API=1, never with -1, and by default from the first timeout gpfq_read_status has
+ *   reported on that device in this process (a shared card), for the rest of the process.
+ * gpfq_clear_contention: forget that timeout for the current device (a host that knows the other tenant has left).
+ */
+unsigned gpfq_spin_limit_word(void);
+int gpfq_coop_launch_api_active(void);
+void gpfq_clear_contention(void);
+
+/*
  * Column preparation: AT[t][k] = A[k][t], XT[t][k] = X[k][t] for k < m, zero for m <= k < m_pad, and
  * nrm2[2t] = ||X[:, t]||_2 ** 2 exactly as step_algorithm.py:142 spells it (sqrt of the sum of squares,
  * squared) with the canonical reduction order, nrm2[2t + 1] = 1 / nrm2[2t] (0 for a zero column; the loop kernels use

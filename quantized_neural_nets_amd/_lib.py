@@ -23,6 +23,7 @@ EXPORTS = [
     "gpfq_row_absmax_f32", "gpfq_describe_plan", "gpfq_quantize_groups_prepared_f32", "gpfq_scratch_bytes",
     "gpfq_read_status", "gpfq_column_norms_f32", "gpfq_gather_patches_f32", "gpfq_last_launch_used_exchange",
     "gpfq_describe_plan_mode", "gpfq_prepare_ws_bytes", "gpfq_prepare_columns_ws_f32", "gpfq_philox_uniform_f32",
+    "gpfq_spin_limit_word", "gpfq_coop_launch_api_active", "gpfq_clear_contention",
 ]
 
 
@@ -70,6 +71,9 @@ def _load():
     lib.gpfq_quantize_groups_prepared_f32.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, i32, i32,
                                                       f32, u64, u64, vp, i32, vp, i32, vp, sz, vp]
     lib.gpfq_last_launch_used_exchange.restype = i32
+    lib.gpfq_spin_limit_word.restype = c.c_uint
+    lib.gpfq_coop_launch_api_active.restype = i32
+    lib.gpfq_clear_contention.restype = None
     lib.gpfq_column_norms_f32.restype = i32
     lib.gpfq_column_norms_f32.argtypes = [vp, i64, i64, i64, vp, vp]
     lib.gpfq_gather_patches_f32.restype = i32

@@ -83,12 +83,18 @@ int env_int(const char* name, int dflt)
 
 int slab_max_waves(bool coop, int RT);
 int resident_max_rt(int waves);
+// the epoch word of a pipelined granule: column + 1 in 20 bits, the launch number in 8, the publisher's XCD in 4
+bool p_d_fits_epoch(int d) { return d < (1 << 20) - 1; }
 
-// GPFQ_COOP_SPIN_LIMIT (polls before an exchange gives up), clamped to what the kernels' 32-bit word can carry scaled by 256
+// GPFQ_COOP_SPIN_LIMIT (polls before an exchange gives up), clamped to what the kernels' 32-bit word can carry scaled by 256.
+// The kernels count `(spins += 256) > limit` with limit = 256 * polls + (pause, < 32): the counter has to be able to EXCEED the
+// limit before it wraps, so the largest poll count is 2^24 - 2 (limit <= 0xFFFFFE1F, spins reaches 0xFFFFFF00 and gives up);
+// at 2^24 - 1 the counter would reach 0xFFFFFF00 <= limit and wrap to 0 on the next poll: an unbounded spin.
+constexpr int kMaxSpinPolls = (1 << 24) - 2;
 int clamped_spin_limit()
 {
     const int v = env_int("GPFQ_COOP_SPIN_LIMIT", kDefaultSpinLimit);
-    return v < 0 ? 0 : (v > (1 << 24) - 1 ? (1 << 24) - 1 : v);
+    return v < 0 ? 0 : (v > kMaxSpinPolls ? kMaxSpinPolls : v);
 }
 
 // Is there an instantiation of the cooperative kernel for (rows per workgroup, sweep waves, members) with this
@@ -189,7 +195,10 @@ double stream_col_cost(int64_t Ng, int S, int cus)
 // Depends on (Ng, S, CU count) only -- never on the data.  cost_out: microseconds per column for all rows.
 bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out, bool allow_rounds);
 
-bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out = nullptr, bool allow_rounds = true)
+// allow_pipe false: the lock-step kernels only -- for layers the pipelined kernels cannot take (2^20 columns or more: their
+// epoch word) and for the retry after a pipelined launch was refused (run_loop)
+bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out = nullptr, bool allow_rounds = true,
+                 bool allow_pipe = true)
 {
     const int force_rt = env_int("GPFQ_COOP_RT", 0), force_c = env_int("GPFQ_COOP_C", 0);
     const int wgs_per_cu = env_int("GPFQ_COOP_WGS_PER_CU", 1) > 1 ? 2 : 1;
@@ -233,7 +242,7 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
     }
     // the pipelined kernels where they are modelled cheaper (GPFQ_COOP_PIPE: 0 never, 1 whenever a configuration exists)
     const int pipe_mode = env_int("GPFQ_COOP_PIPE", -1);
-    if (pipe_mode != 0) {
+    if (pipe_mode != 0 && allow_pipe) {
         Plan pp = *pl;
         double pcost = 0.0;
         // (two sweep waves per member and every row on the chip at once: the lock-step step is already little more than its
@@ -395,7 +404,7 @@ void choose_stream(int64_t Ng, int S, int groups, bool allow_coop, Plan* pl)
     }
 }
 
-int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, int mode, Plan* out)
+int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_scratch, int mode, Plan* out, bool allow_pipe = true)
 {
     Plan pl;
     pl.C = 1; pl.tiles = 0; pl.rounds = 1; pl.tiles_round = 0; pl.grouped = 0; pl.pipe = 0;
@@ -423,7 +432,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
             // are eight rounds of one-row workgroups or four of four-row tiles split in two, 9.5 vs 8.1 us per column)
             const double rcost = resident_step_cost(Ng, pl.S, cus);
             const bool resident_in_rounds = (Ng + pl.RT - 1) / pl.RT > (int64_t)cus * ((pl.S <= 8 ? 8 : (pl.S <= 12 ? 12 : 16)) / pl.S);
-            if (choose_coop(Ng, pl.S, cus, mode, &cp, &ccost, resident_in_rounds) && ccost < 0.97 * rcost) {
+            if (choose_coop(Ng, pl.S, cus, mode, &cp, &ccost, resident_in_rounds, allow_pipe) && ccost < 0.97 * rcost) {
                 *out = cp;
                 return GPFQ_OK;
             }
@@ -443,7 +452,7 @@ int choose_plan(int64_t Ng, int64_t m_pad, int groups, int requested, bool have_
     }
     if (requested == GPFQ_PLAN_COOP || (requested == GPFQ_PLAN_AUTO && !env_int("GPFQ_COOP_DISABLE", 0))) {
         double ccost = 0.0;
-        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, mode, &pl, &ccost)) {
+        if (groups == 1 && have_scratch && choose_coop(Ng, pl.S, cus, mode, &pl, &ccost, true, allow_pipe)) {
             // in rounds only where that beats moving U through memory every column
             if (pl.rounds == 1 || requested == GPFQ_PLAN_COOP || ccost < 0.9 * stream_col_cost(Ng, pl.S, cus)) {
                 *out = pl;
@@ -537,8 +546,9 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.inv_step = fast_ok ? 1.0f / p.qc.step : __builtin_nanf("");
     sp.msq_thr = 0.5f - (p.qc.Kf + 4.0f) * 0x1p-18f;
     // (low FIVE bits: pause before the first poll of an exchange, in units of 256 clocks, 0 .. 31 -- launch_coop, which knows
-    // the kernel; the kernel reads `& 31u`.)  The poll count is clamped to [0, 2^24 - 1] before it is scaled: 256 * 2^24
-    // wraps a 32-bit word to 0 -- every exchange would give up at once -- and a negative value casts to a huge one.
+    // the kernel; the kernel reads `& 31u`.)  The poll count is clamped to [0, 2^24 - 2] before it is scaled: 256 * 2^24
+    // wraps a 32-bit word to 0 -- every exchange would give up at once --, 2^24 - 1 could never be exceeded by a counter that
+    // advances in steps of 256, and a negative value casts to a huge one (clamped_spin_limit).
     sp.spin_limit = 256u * (unsigned)clamped_spin_limit();
     sp.pace = env_int("GPFQ_COOP_PACE", 2);
     sp.xcd_tiles = 0;                               // launch_coop decides
@@ -646,14 +656,50 @@ SlabKernel pipe_kernel_quad(int mode)
     }
 }
 
+// Has a cooperative launch of THIS process timed out on the device (gpfq_read_status saw its status word raised)?  Then the
+// chip is shared with somebody, and every later cooperative grid on that device goes through hipLaunchCooperativeKernel.
+std::atomic<int> g_contended[64];
+
+int current_device_slot()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    return dev;
+}
+
+bool device_contended()
+{
+    const int dev = current_device_slot();
+    return dev >= 0 && g_contended[dev].load(std::memory_order_relaxed) != 0;
+}
+
+void note_contention()
+{
+    const int dev = current_device_slot();
+    if (dev < 0) return;
+    if (g_contended[dev].exchange(1) == 0 && env_int("GPFQ_COOP_LAUNCH_API", 0) >= 0)
+        fprintf(stderr, "gpfq: a cooperative launch timed out on device %d (the card is shared?): the layer is redone on the "
+                        "streaming plan, and cooperative grids on this device are launched through "
+                        "hipLaunchCooperativeKernel from now on\n", dev);
+}
+
+// will the next cooperative grid on the current device go through the cooperative launch API?
+bool use_coop_launch_api()
+{
+    const int mode = env_int("GPFQ_COOP_LAUNCH_API", 0);        // 1 always, -1 never, 0 (default) once contention was seen
+    return mode > 0 || (mode == 0 && device_contended());
+}
+
 // Launch of a grid whose workgroups wait for each other.  Default: a plain launch behind the occupancy check of the caller
 // (the grid is sized to be co-resident on an otherwise idle chip; every spin is bounded and a timeout is reported).
-// GPFQ_COOP_LAUNCH_API=1: hipLaunchCooperativeKernel, with which the RUNTIME refuses a grid that cannot be co-resident
-// (hipErrorCooperativeLaunchTooLarge) instead of letting it spin to its bound -- measured in round 4 (profiles/NOTES.md):
-// adopted only if it costs no more than 2 us per launch.
+// hipLaunchCooperativeKernel, with which the RUNTIME refuses a grid that cannot be co-resident
+// (hipErrorCooperativeLaunchTooLarge) instead of letting it spin to its bound, costs +5 us per launch on the pipelined
+// family (round 4, profiles/NOTES.md) -- so it is not what an undisturbed process pays: it is used from the first timeout
+// this process has seen on the device on (note_contention: a second tenant costs a 2^14-poll spin, ~12 ms, and a streaming
+// redo per cooperative launch, silently, for as long as it stays), or always with GPFQ_COOP_LAUNCH_API=1 (-1: never).
 hipError_t launch_waiting_grid(SlabKernel kern, dim3 grid, dim3 block, size_t shm, hipStream_t st, gpfq::SlabParams& sp)
 {
-    if (env_int("GPFQ_COOP_LAUNCH_API", 0)) {
+    if (use_coop_launch_api()) {
         void* args[] = {&sp};
         return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), grid, block, args, (unsigned)shm, st);
     }
@@ -661,8 +707,6 @@ hipError_t launch_waiting_grid(SlabKernel kern, dim3 grid, dim3 block, size_t sh
     return hipGetLastError();
 }
 
-// the epoch word of a pipelined granule: column + 1 in 20 bits, the launch number in 8, the publisher's XCD in 4
-bool p_d_fits_epoch(int d) { return d < (1 << 20) - 1; }
 
 int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
@@ -822,6 +866,8 @@ int launch_resident(const Plan& pl, const gpfq::SlabParams& sp, int mode, int gr
             nwaves = pl.waves + 1;
         }
     }
+    // (the agent wave exists only together with its share of lines: the kernel takes wave S for the agent)
+    if (nwaves != pl.waves && spx.prefetch_lines < 1) return fail(GPFQ_ERR_UNSUPPORTED, "internal: prefetch agent without lines");
     hipLaunchKernelGGL(k, grid, dim3((unsigned)(64 * nwaves)), shm, st, spx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "GPFQ resident kernel launch");
@@ -857,7 +903,7 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
     if (p.u_has_init && plan == GPFQ_PLAN_AUTO) plan = GPFQ_PLAN_STREAM;
     if (p.u_has_init && plan != GPFQ_PLAN_STREAM && plan != GPFQ_PLAN_STREAM_ROWS)
         return fail(GPFQ_ERR_UNSUPPORTED, "an initial residual needs a streaming plan");
-    int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, p.qc.mode, &pl);
+    int rc = choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, p.qc.mode, &pl, p_d_fits_epoch((int)p.d));
     if (rc) return rc;
     if (groups > 65535) return fail(GPFQ_ERR_UNSUPPORTED, "groups > 65535");
     p.S = pl.S;
@@ -884,7 +930,9 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
         rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, p.qc.mode, &pl);   // does not fit: stream instead
         if (rc) return rc;
     }
-    if (pl.kind == GPFQ_PLAN_COOP) {
+    // (a pipelined configuration the launch refuses -- the occupancy query is the launch's -- gets ONE more try on the lock-step
+    // family, the configuration choose_coop had found for the shape before the pipelined one was modelled cheaper)
+    for (int attempt = 0; attempt < 2 && pl.kind == GPFQ_PLAN_COOP; ++attempt) {
         if (pl.rounds <= 1) {
             rc = launch_slab(pl, p, groups, vec, scratch, st);
         } else {
@@ -905,7 +953,16 @@ int run_loop(gpfq::LoopParams p, int groups, int plan, void* scratch, size_t scr
             }
         }
         if (rc == GPFQ_OK) g_used_exchange = 1;
-        if (rc != GPFQ_ERR_UNSUPPORTED || plan == GPFQ_PLAN_COOP) return rc;
+        if (rc != GPFQ_ERR_UNSUPPORTED) return rc;
+        const bool was_pipe = pl.pipe != 0;
+        if (was_pipe && attempt == 0) {
+            Plan lp;
+            if (choose_plan(p.Ng, p.m_pad, groups, plan, have_scratch, p.qc.mode, &lp, false) == GPFQ_OK && lp.kind == GPFQ_PLAN_COOP && !lp.pipe) {
+                pl = lp;
+                continue;
+            }
+        }
+        if (plan == GPFQ_PLAN_COOP) return rc;
         rc = choose_plan(p.Ng, p.m_pad, groups, GPFQ_PLAN_STREAM, have_scratch, p.qc.mode, &pl);   // does not fit: stream instead
         if (rc) return rc;
     }
@@ -942,6 +999,16 @@ extern "C" {
 int gpfq_abi_version(void) { return GPFQ_ABI_VERSION; }
 
 int gpfq_last_launch_used_exchange(void) { return g_used_exchange; }
+
+unsigned gpfq_spin_limit_word(void) { return 256u * (unsigned)clamped_spin_limit(); }
+
+int gpfq_coop_launch_api_active(void) { return use_coop_launch_api() ? 1 : 0; }
+
+void gpfq_clear_contention(void)
+{
+    const int dev = current_device_slot();
+    if (dev >= 0) g_contended[dev].store(0);
+}
 
 const char* gpfq_last_error(void) { return g_err.c_str(); }
 
@@ -986,6 +1053,7 @@ int gpfq_read_status(void* scratch, int* status_host4, void* stream)
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail(e, "status read");
     if (status_host4[0] != 0) {
+        note_contention();
         e = hipMemsetAsync(sp, 0, 4 * sizeof(int), st);
         if (e != hipSuccess) return hip_fail(e, "status reset");
         return fail(GPFQ_ERR_TIMEOUT, "cooperative kernel timed out waiting for a peer workgroup");
@@ -1261,7 +1329,7 @@ int gpfq_describe_plan_mode(int64_t N, int64_t d_g, int64_t m, int groups, int p
     if (groups < 1 || N % groups != 0) return fail(GPFQ_ERR_ARG, "bad groups");
     if (mode < 0 || mode > 3) return fail(GPFQ_ERR_ARG, "mode must be 0..3");
     Plan pl;
-    int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, mode, &pl);
+    int rc = choose_plan(N / groups, gpfq_padded_m(m), groups, plan, true, mode, &pl, d_g < 0 || p_d_fits_epoch((int)(d_g > 0x7fffffff ? 0x7fffffff : d_g)));
     if (rc) return rc;
     if (buf && buf_bytes) {
         if (pl.kind == GPFQ_PLAN_COOP && pl.grouped)

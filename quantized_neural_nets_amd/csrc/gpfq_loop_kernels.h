@@ -934,17 +934,30 @@ GPFQ_DEFINE_COOP_GROUPED(0) GPFQ_DEFINE_COOP_GROUPED(1) GPFQ_DEFINE_COOP_GROUPED
 // instructions per step -- an uncoalesced load occupies the CU's address unit for as long as 64 separate ones, those eight
 // workgroups fell behind and the layer went from 0.77 to 0.98 us per column.)  The loads land in a window register nobody
 // reads; nothing waits for them.
+// The ONE barrier of a resident step.  The sweep waves (resident_body::step) and the prefetch agent, which returns early and
+// never sweeps, meet at it: both MUST pass exactly one per column and none outside the column loop -- a second or a
+// conditional barrier in the step would not hang (ended waves drop out of barriers) but let the sweep waves run past
+// segment sums that have not been written.  So both name it through these two helpers and nothing else in the resident
+// kernels may synchronise the workgroup (tests/test_gpu_prefetch_agent.py runs every (rows, wave bound) variant with the
+// agent against the oracle).
+__device__ __forceinline__ void resident_step_barrier() { __syncthreads(); }
+// (the agent has nothing in LDS and a load in flight that must NOT be waited for: lgkmcnt only)
+__device__ __forceinline__ void resident_agent_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int WB>
 __device__ __forceinline__ void resident_prefetch_agent(const SlabParams& p, int g, int lane)
 {
     const int K = p.prefetch_ahead;
     const int S = p.S;
-    const int LP = p.prefetch_lines;                             // lines of a segment this workgroup touches (1 with 32+ workgroups per XCD)
+    // lines of a segment this workgroup touches (1 with 32+ workgroups per XCD); a launch with an agent wave but no lines
+    // (the host never makes one: launch_resident) leaves the agent to pass the barriers and touch nothing
+    const bool any = p.prefetch_lines > 0;
+    const int LP = any ? p.prefetch_lines : 1;
     const int W = 32 / LP;                                       // workgroups of an XCD that share a segment's 32 lines
     const int64_t col_bytes = p.m_pad * (int64_t)sizeof(float);
     const unsigned j = (blockIdx.x >> 3) % (unsigned)W;          // this workgroup's share
     const int per_matrix = S * LP;
-    const bool mine = lane < 2 * per_matrix;
+    const bool mine = any && lane < 2 * per_matrix;
     const int rem = lane < per_matrix ? lane : lane - per_matrix;
     const unsigned line = j + (unsigned)(rem % LP) * (unsigned)W;
     const char* base = reinterpret_cast<const char*>((lane < per_matrix ? p.XT : p.AT) + (int64_t)g * p.d * p.m_pad) +
@@ -953,7 +966,7 @@ __device__ __forceinline__ void resident_prefetch_agent(const SlabParams& p, int
         const int tc = t + K;
         if (mine && tc < p.d)
             asm volatile("global_load_dword v[%c1], %0, off" :: "v"(base + tc * col_bytes), "n"(WB) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the step's one barrier
+        resident_agent_barrier();                                       // the step's one barrier
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1086,7 +1099,7 @@ __device__ __forceinline__ void resident_body(const SlabParams& p)
         win_load4<XP, 1, NQ>(xload, lane_off);
         win_load4<AC, 1, NQ>(aload, lane_off);
         GPFQ_RSTAMP(3)
-        if constexpr (!ONE) __syncthreads();
+        if constexpr (!ONE) resident_step_barrier();
         GPFQ_RSTAMP(4)
         win_load4<XP, 2, NQ>(xload, lane_off);
         win_load4<AC, 2, NQ>(aload, lane_off);

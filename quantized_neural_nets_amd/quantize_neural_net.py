@@ -35,6 +35,13 @@ LAYER_LOGGING = False
 # time in a process that has imported torch: 3 x 54 layers = 6.5 s of a 12 s ResNet-50 run (bench.py --driver r50).
 # True restores the reference's calls.
 COLLECT_GARBAGE_PER_LAYER = False
+# ... and what stands in for them by default: a model or hook that holds reference CYCLES (user models run through
+# compat/run_main.py may) keeps captured activations alive until the cyclic collector's generational thresholds happen to
+# trigger.  So after every layer the device memory in use is compared with the lowest level seen after any layer so far, and
+# ONE full collection runs when it has grown by more than this many bytes (torch.cuda.memory_allocated: a counter, no
+# synchronisation).  A driver without cycles returns to its low-water mark after every layer and never pays; one with cycles
+# pays ~40 ms when -- and only when -- a couple of layers' worth of activations have piled up.  0 switches the check off.
+GC_WHEN_DEVICE_MEMORY_GROWS_BY = 2 << 30
 # Conv2d capture: gather the sampled patches on the GPU straight into the kernels' column layout
 # (gpfq_gather_patches_f32) instead of materialising the full unfold and transposing it afterwards.
 FUSED_CAPTURE = True
@@ -107,6 +114,9 @@ class QuantizeNeuralNet:
 
         ahead = None                 # (layer index, raw batch, hook) of the layer whose analog capture is already under way
         side = None
+        on_gpu = torch.cuda.is_available() and torch.device(self.device).type == 'cuda'
+        low_water = None             # least device memory in use seen after a layer (GC_WHEN_DEVICE_MEMORY_GROWS_BY)
+        self.garbage_collections = 0
         if self.prefetch_analog and torch.cuda.is_available() and torch.device(self.device).type == 'cuda':
             side = torch.cuda.Stream(device=self.device)
         for done, layer_idx in enumerate(todo):
@@ -172,9 +182,16 @@ class QuantizeNeuralNet:
             if LAYER_LOGGING:
                 self._log_layer(layer_idx, W, Q, quantize_adder, relative_adder)
 
-            del analog_in, quantized_in
+            del analog_in, quantized_in, res, Q, quantize_adder, relative_adder
             if COLLECT_GARBAGE_PER_LAYER:
                 gc.collect()
+            elif on_gpu and GC_WHEN_DEVICE_MEMORY_GROWS_BY > 0:
+                in_use = torch.cuda.memory_allocated(self.device)
+                if low_water is not None and in_use - low_water > GC_WHEN_DEVICE_MEMORY_GROWS_BY:
+                    gc.collect()
+                    self.garbage_collections += 1
+                    in_use = torch.cuda.memory_allocated(self.device)
+                low_water = in_use if low_water is None else min(low_water, in_use)
             self._mark("layer_end", layer_idx)
         return self.quantized_network
 

@@ -304,7 +304,6 @@ class StepAlgorithm:
         idx_dtype, idx_bytes = _idx_dtype(K)
         dev = W.device
         st = _lib.current_stream_ptr(dev)
-        scr = None                                   # taken under the device's lock, below
 
         def run_rows(W_loc, groups_loc, A_loc, lda_loc, X_loc, ldx_loc, row_id0):
             """all groups of a (sub)layer in one launch; returns Q, idx, U for those rows"""
@@ -344,38 +343,41 @@ class StepAlgorithm:
                     _ptr(AT), _ptr(XT), _ptr(nrm2), mp, _ptr(part), part.numel() * 4, st))
             if hook:
                 hook("loop_begin", (Nl, dg, mm, groups_loc))
-            def launch(pl):
+            def launch(pl, scr):
                 _lib.check(_lib.lib.gpfq_quantize_groups_prepared_f32(
                     _ptr(W_loc), _ptr(Q), _ptr(U), _ptr(AT), _ptr(XT), _ptr(nrm2), Nl, dg, mm, mp, groups_loc,
                     step, K, mode, lamb_f, seed, int(row_id0), _ptr(idx), idx_bytes, _ptr(usq_seg), pl,
                     _ptr(scr), scr.numel(), st))
                 return bool(_lib.lib.gpfq_last_launch_used_exchange())
 
-            waits = launch(plan)
-            if hook:
-                hook("loop_end", (Nl, dg, mm, groups_loc))
-            # A plan whose workgroups wait for each other can give up (bounded spins: another process on the card can
-            # break co-residency).  Its outputs are not handed on -- to the caller, to the all_gather -- before the
-            # status word has been read, and a timed-out layer is redone on the plan that waits for nobody.  The other
-            # plans (resident, wave, whole-row streaming) cannot time out and cost no synchronisation here.
-            if waits and check_status and not _lib.status_ok(dev):
-                timeouts.append((Nl, dg, mm))
-                launch(_lib.PLAN_STREAM_ROWS)
+            # scratch -> launch -> status read (-> redo) under the device's lock (_lib.exclusive): the scratch area, its
+            # granules and its status words are one per device, and two host threads on two streams must neither run two
+            # cooperative grids on them at once nor read each other's timeout.  The lock covers THIS launch only -- not the
+            # column preparation above, and never a collective: with neuron sharding the caller (dist.quantize_sharded) goes
+            # on to an all_gather, and a rank that held the device's lock while blocked in it would deadlock against a peer
+            # rank living in another thread of the same process, on the same card, waiting for that lock.
+            with _lib.exclusive(dev):
+                scr = _lib.scratch(dev)
+                waits = launch(plan, scr)
+                if hook:
+                    hook("loop_end", (Nl, dg, mm, groups_loc))
+                # A plan whose workgroups wait for each other can give up (bounded spins: another process on the card can
+                # break co-residency).  Its outputs are not handed on -- to the caller, to the all_gather -- before the
+                # status word has been read, and a timed-out layer is redone on the plan that waits for nobody.  The other
+                # plans (resident, wave, whole-row streaming) cannot time out and cost no synchronisation here.
+                if waits and check_status and not _lib.status_ok(dev):
+                    timeouts.append((Nl, dg, mm))
+                    launch(_lib.PLAN_STREAM_ROWS, scr)
             return Q, idx, U, usq_seg
 
         timeouts = []
         shard = _dist.active()
-        # scratch -> launches -> status reads under the device's lock (_lib.exclusive): the scratch area, its granules and
-        # its status words are one per device, and two host threads on two streams must neither run two cooperative grids
-        # on them at once nor read each other's timeout
-        with _lib.exclusive(dev):
-            scr = _lib.scratch(dev)
-            if shard is None:
-                Q, idx, U, usq_seg = run_rows(W, groups, A, lda, X, ldx, 0)
-                rows = None
-            else:
-                Q, idx, U, usq_seg, rows = _dist.quantize_sharded(shard, W, A, lda, X, ldx, groups, dg, step, K, mode,
-                                                                  lamb_f, idx_dtype, run_rows)
+        if shard is None:
+            Q, idx, U, usq_seg = run_rows(W, groups, A, lda, X, ldx, 0)
+            rows = None
+        else:
+            Q, idx, U, usq_seg, rows = _dist.quantize_sharded(shard, W, A, lda, X, ldx, groups, dg, step, K, mode,
+                                                              lamb_f, idx_dtype, run_rows)
         out = dict(Q=Q, idx=idx, U=U, usq_seg=usq_seg, step=step_t, rows=rows, timeouts=timeouts)
         if compute_errors:
             out.update(StepAlgorithm._error_metrics(W, A, usq_seg, groups, rows, shard, U))

@@ -18,3 +18,13 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(autouse=True)
+def _forget_forced_timeouts():
+    """Tests that force a cooperative timeout (GPFQ_COOP_SPIN_LIMIT=0) throw the device's launch-API switch
+    (gpfq_capi.hip note_contention): clear it behind every test so that each starts from the undisturbed default."""
+    yield
+    mod = sys.modules.get("quantized_neural_nets_amd._lib")
+    if mod is not None:
+        mod.lib.gpfq_clear_contention()

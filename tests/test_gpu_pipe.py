@@ -108,6 +108,48 @@ def test_pipelined_timeout_is_reported_and_the_layer_redone(oracle_mod, monkeypa
     assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx) and np.array_equal(r["U"].cpu().numpy(), U)
     monkeypatch.delenv("GPFQ_COOP_SPIN_LIMIT")
     assert _run(W, A, X, m, 0, step=step)["timeouts"] == []
+    _lib.lib.gpfq_clear_contention()                     # (the forced timeout threw the device's launch-API switch)
+
+
+def test_first_timeout_switches_the_device_to_the_cooperative_launch_api(oracle_mod, monkeypatch, capfd):
+    """Contention fails fast without taxing the common case: an undisturbed process launches its cooperative grids plainly;
+    the first timeout its status read reports on a device (here forced: spin limit 0) is logged once and switches every
+    later cooperative launch on that device to hipLaunchCooperativeKernel -- same kernels, same bits -- until
+    gpfq_clear_contention."""
+    from quantized_neural_nets_amd import _lib
+    L = _lib.lib
+    monkeypatch.delenv("GPFQ_COOP_LAUNCH_API", raising=False)
+    L.gpfq_clear_contention()
+    assert L.gpfq_coop_launch_api_active() == 0
+    results = {}
+    for (N, d, m, want) in ((64, 12, 93184, "pipe=1"), (64, 9, 23296, "coop RT=2 C=8")):
+        assert want in _lib.describe_plan(N, d, m)
+        W, A, X = bw.synthetic_layer(N, d, m, 31 + N + d, first_layer=False)
+        step = bw.layer_step(W)
+        results[(N, d, m)] = (W, A, X, step, _run(W, A, X, m, 0, step=step))
+        assert results[(N, d, m)][4]["timeouts"] == [] and L.gpfq_coop_launch_api_active() == 0
+    # the first cooperative launch times out -> redone on the streaming plan, the switch is thrown and logged ONCE
+    (N, d, m), (W, A, X, step, ref) = next(iter(results.items()))
+    monkeypatch.setenv("GPFQ_COOP_SPIN_LIMIT", "0")
+    capfd.readouterr()
+    r = _run(W, A, X, m, 0, step=step)
+    assert r["timeouts"] == [(N, d, m)] and torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"])
+    r = _run(W, A, X, m, 0, step=step)                   # a second timeout: no second line
+    assert r["timeouts"] == [(N, d, m)]
+    monkeypatch.delenv("GPFQ_COOP_SPIN_LIMIT")
+    assert capfd.readouterr().err.count("hipLaunchCooperativeKernel from now on") == 1
+    assert L.gpfq_coop_launch_api_active() == 1
+    # the next cooperative launches go through the cooperative API: same bits, both families, oracle-equal
+    for (N, d, m), (W, A, X, step, ref) in results.items():
+        r = _run(W, A, X, m, 0, step=step)
+        assert r["timeouts"] == [] and torch.equal(r["idx"], ref["idx"]) and torch.equal(r["U"], ref["U"])
+        Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8)
+        assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx) and np.array_equal(r["U"].cpu().numpy(), U)
+    monkeypatch.setenv("GPFQ_COOP_LAUNCH_API", "-1")     # never
+    assert L.gpfq_coop_launch_api_active() == 0
+    monkeypatch.delenv("GPFQ_COOP_LAUNCH_API")
+    L.gpfq_clear_contention()
+    assert L.gpfq_coop_launch_api_active() == 0
 
 
 def test_classic_lock_step_kernels_stay_selectable(monkeypatch):

@@ -59,6 +59,44 @@ def test_host_side_argument_errors_need_no_gpu(lib):
     assert rc == -1 and b"int8" in L.gpfq_last_error()                                # K too big for int8
 
 
+def test_spin_limit_word_can_always_be_exceeded_before_the_counter_wraps(lib, monkeypatch):
+    """The kernels bound an exchange with `(spins += 256) > word + pause` on a 32-bit counter (gpfq_loop_kernels.h
+    reducer_section, gpfq_pipe_kernels.h pipe_reducer; pause < 32).  At the clamp the counter must still be able to exceed
+    the word: with 2^24 - 1 polls it reached 0xFFFFFF00, which is not greater, and wrapped to 0 -- an unbounded spin."""
+    L = lib.lib
+    for asked, polls in (("16384", 16384), ("0", 0), ("-5", 0), (str((1 << 24) - 2), (1 << 24) - 2),
+                         (str((1 << 24) - 1), (1 << 24) - 2), (str(1 << 30), (1 << 24) - 2)):
+        monkeypatch.setenv("GPFQ_COOP_SPIN_LIMIT", asked)
+        word = L.gpfq_spin_limit_word()
+        assert word == 256 * polls, (asked, word)
+        for pause in (0, 31):
+            limit = word | pause
+            # the last value the counter takes before it would wrap: a multiple of 256 below 2^32
+            assert 0xFFFFFF00 > limit, (asked, hex(limit))
+            # ... and the kernel's loop, replayed from the last few polls before the bound: it gives up without wrapping
+            spins, gave_up = max(0, (limit & ~255) - 512), False
+            for _ in range(8):
+                spins = (spins + 256) & 0xFFFFFFFF
+                if spins > limit:
+                    gave_up = True
+                    break
+                assert spins != 0, "the counter wrapped"
+            assert gave_up
+    monkeypatch.delenv("GPFQ_COOP_SPIN_LIMIT")
+    assert L.gpfq_spin_limit_word() == 256 * 16384
+
+
+def test_cooperative_launch_api_is_off_until_asked_for_or_contention_is_seen(lib, monkeypatch):
+    L = lib.lib
+    monkeypatch.delenv("GPFQ_COOP_LAUNCH_API", raising=False)
+    L.gpfq_clear_contention()
+    assert L.gpfq_coop_launch_api_active() == 0          # (the sticky switch itself needs a timeout: tests/test_gpu_pipe.py)
+    monkeypatch.setenv("GPFQ_COOP_LAUNCH_API", "1")
+    assert L.gpfq_coop_launch_api_active() == 1
+    monkeypatch.setenv("GPFQ_COOP_LAUNCH_API", "-1")
+    assert L.gpfq_coop_launch_api_active() == 0
+
+
 def test_plan_selection(lib):
     assert lib.describe_plan(512, 4608, 3072).startswith("resident")
     assert lib.describe_plan(256, 2304, 7168).startswith("resident")
