@@ -77,7 +77,7 @@ def parse_args():
     ap.add_argument("--prefetch-analog", action="store_true",
                     help="prepare the ANALOG columns of layer i+1 on a side stream while the loop of layer i runs (they do not "
                          "depend on the layers quantized before; the quantized columns stay serial, as in the real driver)")
-    ap.add_argument("--driver", default=None, choices=["r18", "r50"],
+    ap.add_argument("--driver", default=None, choices=["r18", "r50", "vgg16", "effnet_b1"],
                     help="time QuantizeNeuralNet.quantize_network() itself -- what the reference's main.py:120-125 times -- on a "
                          "builder-owned ResNet-18 (batch 256) / ResNet-50 (batch 1024) with random weights and synthetic "
                          "images, and print the split forward / capture / preparation / loop / metrics / write-back")
@@ -396,10 +396,19 @@ def counter_rooflines(dom, fam_rec, digest, l2_model):
     return {"issue": issue, "l2": l2}, src
 
 
+DRIVER_CONFIGS = {
+    # --driver name: (architecture, BASELINE.json calibration batch, bits, reg, lamb)
+    "r18": ("resnet18", 256, 4, None, 0.1),
+    "r50": ("resnet50", 1024, 4, None, 0.1),
+    "vgg16": ("vgg16", 512, 4, None, 0.1),
+    "effnet_b1": ("efficientnet_b1", 1024, 2, "L1", 0.1),          # sparse GPFQ (main.py:34-36: -reg L1, default lambda 0.1)
+}
+
+
 def driver_bench(args):
-    """`--driver r18|r50`: ONE call of QuantizeNeuralNet.quantize_network() on a real block architecture at the config's
-    calibration batch (BASELINE.json configs 1 and 3 on one GPU), wall-clocked the way the reference's main.py:120-125
-    clocks it, and split by stream events at the driver's phase boundaries (QuantizeNeuralNet.timing_hook):
+    """`--driver r18|r50|vgg16|effnet_b1`: ONE call of QuantizeNeuralNet.quantize_network() on a real block architecture at
+    the config's calibration batch (BASELINE.json configs 1-4 on one GPU), wall-clocked the way the reference's
+    main.py:120-125 clocks it, and split by stream events at the driver's phase boundaries (QuantizeNeuralNet.timing_hook):
       forward     the two partial forwards per layer up to the hooked layer (quantize_neural_net.py:256-269)
       capture     the hooks: patch sampling (np.random.choice per image) + the fused gather into the column layout (:325-350)
       prepare     column preparation still missing behind the capture (norms; transposes for Linear layers)
@@ -408,23 +417,50 @@ def driver_bench(args):
       write_back  Q into the quantized network, the two printed errors (.cpu(): a sync), the index copy for packed.save
       between     host work between layers: the loader's next batch, prints (the reference's three gc.collect() per layer,
                   :137 / :212 / :271, are off by default here: quantize_neural_net.COLLECT_GARBAGE_PER_LAYER)
-    Random-init weights and random images (no checkpoints, no ImageNet here): the loop's cost does not depend on values."""
+    Random-init weights and random images (no checkpoints, no ImageNet here): the loop's cost does not depend on values.
+    ORACLE LEG (after the timed call): for a handful of layers spread over the network (and the first grouped one) the
+    driver's indices for a few rows x 24 columns are compared with the CPU oracle on the inputs the hooks captured in THIS
+    run -- the slices are cloned on the device inside the run (microseconds) and checked once the clock has stopped."""
     import contextlib
     import numpy as np
     import torch
-    from quantized_neural_nets_amd import QuantizeNeuralNet, arch
+    from quantized_neural_nets_amd import QuantizeNeuralNet, StepAlgorithm, arch
     from quantized_neural_nets_amd.main import SyntheticLoader
+    from quantized_neural_nets_amd.step_algorithm import PreparedColumns
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     dev = torch.device("cuda", 0)
-    name, named_batch = {"r18": ("resnet18", 256), "r50": ("resnet50", 1024)}[args.driver]
+    name, named_batch, bits, reg, lamb = DRIVER_CONFIGS[args.driver]
     batch = args.batch or named_batch
     torch.manual_seed(0)
     np.random.seed(0)
     model = arch.ARCHITECTURES[name]().to(dev).eval()
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("GPFQ_DRIVER_CONV_BENCHMARK", "0")))
-    q = QuantizeNeuralNet(model, name, batch, SyntheticLoader(batch, 224, 1, device=dev), mlp_bits=4, cnn_bits=4, ignore_layers=[],
-                          mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16, mlp_percentile=1, cnn_percentile=1, reg=None,
-                          lamb=0.1, retain_rate=0.25, stochastic_quantization=False, device=dev)
+    q = QuantizeNeuralNet(model, name, batch, SyntheticLoader(batch, 224, 1, device=dev), mlp_bits=bits, cnn_bits=bits, ignore_layers=[],
+                          mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16, mlp_percentile=1, cnn_percentile=1, reg=reg,
+                          lamb=lamb, retain_rate=0.25, stochastic_quantization=False, device=dev)
+    # the oracle leg's samples: six layers spread evenly over the network + the first grouped conv, a few rows x 24 columns
+    nl = len(q.quantized_network_layers)
+    picked = sorted({int(round(i * (nl - 1) / 5.0)) for i in range(6)} |
+                    {next((i for i, l in enumerate(q.analog_network_layers) if getattr(l, "groups", 1) > 1), 0)})
+    samples, calls = [], [0]
+    real_layer = StepAlgorithm._quantize_layer_ex
+
+    def sampling_layer(W, A, X, m, step_size, K, pct, reg_, lamb_, groups, stochastic, device, **kw):
+        res = real_layer(W, A, X, m, step_size, K, pct, reg_, lamb_, groups, stochastic, device, **kw)
+        li = calls[0]
+        calls[0] += 1
+        if li in picked:
+            N, dg = W.shape
+            Ng, cols = N // groups, min(dg, 24)
+            Am = A.matrix() if isinstance(A, PreparedColumns) else A
+            Xm = X.matrix() if isinstance(X, PreparedColumns) else X
+            for g in sorted({0, groups - 1}):
+                rows = sorted(set(list(range(min(Ng, 3))) + list(range(max(Ng - 3, 0), Ng))))
+                ridx = torch.tensor([g * Ng + r for r in rows], device=W.device)
+                samples.append(dict(layer=li, group=g, K=int(K), step=float(res["step"]),
+                                    W=W.index_select(0, ridx)[:, :cols].clone(), A=Am[:, g * dg:g * dg + cols].clone(),
+                                    X=Xm[:, g * dg:g * dg + cols].clone(), idx=res["idx"].index_select(0, ridx)[:, :cols].clone()))
+        return res
     # one untimed forward of a full batch: the convolution library picks (and, on a fresh box, builds) its kernels here
     # rather than inside the timed call
     t0 = time.perf_counter()
@@ -442,10 +478,28 @@ def driver_bench(args):
     q.timing_hook = mark
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    with contextlib.redirect_stdout(sys.stderr):         # the driver prints per layer, like the reference
-        q.quantize_network()
+    StepAlgorithm._quantize_layer_ex = sampling_layer
+    try:
+        with contextlib.redirect_stdout(sys.stderr):     # the driver prints per layer, like the reference
+            q.quantize_network()
+    finally:
+        StepAlgorithm._quantize_layer_ex = real_layer
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    # ---- the oracle leg (the clock has stopped)
+    sys.path.insert(0, ROOT)
+    import oracle
+    omode = {None: 0, "L1": 1, "L0": 2}[reg]
+    ocheck = {"layers": sorted({sm["layer"] for sm in samples}), "weights": 0, "mismatches": 0,
+              "what": "driver indices of the first / last rows x 24 columns of these layers (first and last group of a grouped "
+                      "conv) against oracle.quantization on the inputs the hooks captured in this run"}
+    for sm in samples:
+        _, idx_o, _ = oracle.quantization(sm["W"].cpu().numpy(), sm["A"].cpu().numpy(), sm["X"].cpu().numpy(), sm["step"], sm["K"],
+                                          mode=omode, lamb=float(lamb))
+        got = sm["idx"].cpu().numpy().astype(np.int16)
+        ocheck["weights"] += int(got.size)
+        ocheck["mismatches"] += int((got != idx_o).sum())
+    del samples
     phase_of = {("forward_begin", "capture_begin"): "forward", ("capture_begin", "capture_end"): "capture",
                 ("prepare_begin", "loop_begin"): "prepare", ("loop_begin", "loop_end"): "loop",
                 ("loop_end", "metrics_end"): "metrics", ("metrics_end", "layer_end"): "write_back",
@@ -473,8 +527,11 @@ def driver_bench(args):
                      % (name, len(q.quantized_network_layers), batch),
            "value": round(wall, 4), "unit": "s", "higher_is_better": False, "n_gpus": 1, "dtype": "f32",
            "data": "synthetic (random-init weights, random images)",
-           "config": {"workload": "%s (builder-owned architecture, arch.py), 4-bit, scalar 1.16, retain_rate 0.25, batch %d" % (name, batch),
+           "config": {"workload": "%s (builder-owned architecture, arch.py), %d-bit%s, scalar 1.16, retain_rate 0.25, batch %d" % (
+                          name, bits, (", reg %s lamb %g" % (reg, lamb)) if reg else "", batch),
                       "layers": len(q.quantized_network_layers), "weights": weights},
+           "oracle_check": ocheck,
+           "garbage_collections": getattr(q, "garbage_collections", 0),
            "weights_per_s_wall_M": round(weights / wall / 1e6, 3),
            "split_ms": {k: round(v, 2) for k, v in split.items()},
            "split_share": {k: round(v / total_ev, 4) for k, v in split.items()},
@@ -487,6 +544,8 @@ def driver_bench(args):
            "relative_quantize_error_range": [round(min(r["relative_quantize_error"] for r in q.layer_reports), 5),
                                              round(max(r["relative_quantize_error"] for r in q.layer_reports), 5)]}
     print(json.dumps(out), flush=True)
+    if ocheck["mismatches"]:
+        raise SystemExit("driver bench: %d of %d sampled indices differ from the oracle" % (ocheck["mismatches"], ocheck["weights"]))
 
 
 def main():
@@ -713,6 +772,11 @@ def main():
             nchk += r["idx"].numel()
             nlay += 1
         output_check = {"against": "rerun on the streaming kernel family", "layers": nlay, "weights": nchk, "mismatches": nbad}
+        if pg:
+            # every rank checks the gathered indices it holds; the line rank 0 prints carries the sum over the ranks
+            tot = torch.tensor([nbad, nchk], device=dev if args.backend == "nccl" else "cpu", dtype=torch.int64)
+            td.all_reduce(tot)
+            output_check.update(ranks=world, mismatches_all_ranks=int(tot[0].item()), weights_all_ranks=int(tot[1].item()))
         if rank == 0:
             log("output check: %d layers, %d weights, %d index mismatches vs the streaming rerun" % (nlay, nchk, nbad))
 
@@ -886,7 +950,7 @@ def main():
                                              "/ 8 TB/s; a plain device copy of such sizes reaches 5.3 TB/s = 0.66 (tools/scratch/copy_rate.py)"}),
             "output_check": output_check,
         }
-        failed = bool(output_check and output_check["mismatches"])
+        failed = bool(output_check and (output_check["mismatches"] or output_check.get("mismatches_all_ranks", 0)))
         if not args.no_output_check and not args.capture and args.oracle_budget > 0:
             out["oracle_shape_check"] = oracle_shape_check(data, layers, last_idx, K, mode, lamb, args.oracle_budget)
             failed = failed or bool(out["oracle_shape_check"]["mismatches"])

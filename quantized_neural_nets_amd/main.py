@@ -87,9 +87,9 @@ def load_model(name, data_set='ILSVRC2012'):
         if name == 'alexnet':
             return AlexNetArch(), False
         from .arch import ARCHITECTURES
-        if name in ARCHITECTURES:                   # builder-owned ResNet-18 / ResNet-50 definitions, random init
+        if name in ARCHITECTURES:                   # builder-owned definitions (arch.py), random init
             return ARCHITECTURES[name](), False
-        raise SystemExit("torchvision is not installed: only `-model alexnet`, `resnet18` and `resnet50` (random init) are available")
+        raise SystemExit("torchvision is not installed: only `-model alexnet` and %s (random init) are available" % ", ".join(sorted(ARCHITECTURES)))
 
 
 class SyntheticLoader:

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(model_name, batch, fused, oracle_mod=None, seed=0, max_check_cols=24):
+def _run(model_name, batch, fused, oracle_mod=None, seed=0, max_check_cols=24, bits=4, reg=None, lamb=0.1):
     import quantized_neural_nets_amd.quantize_neural_net as qnn_mod
     from quantized_neural_nets_amd import QuantizeNeuralNet, StepAlgorithm, arch
     from quantized_neural_nets_amd.main import SyntheticLoader
@@ -29,10 +29,11 @@ def _run(model_name, batch, fused, oracle_mod=None, seed=0, max_check_cols=24):
     torch.manual_seed(seed)
     np.random.seed(seed)
     model = arch.ARCHITECTURES[model_name]().to(DEV).eval()
-    q = QuantizeNeuralNet(model, model_name, batch, SyntheticLoader(batch, 224, seed + 1), mlp_bits=4, cnn_bits=4,
+    q = QuantizeNeuralNet(model, model_name, batch, SyntheticLoader(batch, 224, seed + 1), mlp_bits=bits, cnn_bits=bits,
                           ignore_layers=[], mlp_alphabet_scalar=1.16, cnn_alphabet_scalar=1.16, mlp_percentile=1,
-                          cnn_percentile=1, reg=None, lamb=0.1, retain_rate=0.25, stochastic_quantization=False,
+                          cnn_percentile=1, reg=reg, lamb=lamb, retain_rate=0.25, stochastic_quantization=False,
                           device=torch.device(DEV))
+    omode = {None: 0, "L1": 1, "L0": 2}[reg]
     real = StepAlgorithm._quantize_layer_ex
     seen, stats = set(), dict(shapes=0, weights=0, mismatches=0, calls=0)
 
@@ -42,19 +43,25 @@ def _run(model_name, batch, fused, oracle_mod=None, seed=0, max_check_cols=24):
         key = (tuple(W.shape), int(m), int(groups))
         if oracle_mod is not None and key not in seen:
             seen.add(key)
-            N, d = W.shape
-            rows = sorted(set(list(range(min(N, 4))) + list(range(max(N - 4, 0), N))))
+            N, d = W.shape                       # d = columns of ONE group (step_algorithm.py:223-230)
+            Ng = N // groups
             cols = min(d, max_check_cols)
             Am = A.matrix() if isinstance(A, PreparedColumns) else A
             Xm = X.matrix() if isinstance(X, PreparedColumns) else X
-            assert Am.shape == (m, d) and Xm.shape == (m, d)
-            ridx = torch.tensor(rows, device=W.device)
-            _, idx_o, _ = oracle_mod.quantization(W.index_select(0, ridx)[:, :cols].cpu().numpy(), Am[:, :cols].cpu().numpy(),
-                                                  Xm[:, :cols].cpu().numpy(), float(res["step"]), K)
-            got = res["idx"].index_select(0, ridx)[:, :cols].cpu().numpy().astype(np.int16)
+            assert Am.shape == (m, groups * d) and Xm.shape == (m, groups * d)
             stats["shapes"] += 1
-            stats["weights"] += got.size
-            stats["mismatches"] += int((got != idx_o).sum())
+            stats["grouped"] = stats.get("grouped", 0) + (groups > 1)
+            # first and last rows of the first and the last group (groups == 1: of the layer), each group against its OWN
+            # block of input columns (step_algorithm.py:228-237)
+            for g in sorted({0, groups - 1}):
+                rows = sorted(set(list(range(min(Ng, 4))) + list(range(max(Ng - 4, 0), Ng))))
+                ridx = torch.tensor([g * Ng + r for r in rows], device=W.device)
+                _, idx_o, _ = oracle_mod.quantization(W.index_select(0, ridx)[:, :cols].cpu().numpy(),
+                                                      Am[:, g * d:g * d + cols].cpu().numpy(), Xm[:, g * d:g * d + cols].cpu().numpy(),
+                                                      float(res["step"]), K, mode=omode, lamb=float(lamb))
+                got = res["idx"].index_select(0, ridx)[:, :cols].cpu().numpy().astype(np.int16)
+                stats["weights"] += got.size
+                stats["mismatches"] += int((got != idx_o).sum())
         return res
 
     old_fused = qnn_mod.FUSED_CAPTURE
@@ -91,5 +98,46 @@ def test_block_architecture_through_the_driver(model_name, batch, nlayers, oracl
     assert "Quantizing layer with index: %d" % (nlayers - 1) in out
     # the same run with the reference's capture op sequence (unfold, transpose, reshape, index) instead of the fused gather
     q2, _ = _run(model_name, batch, False)
+    for a, b in zip(q.quantized_network_layers, q2.quantized_network_layers):
+        assert torch.equal(a.weight, b.weight)
+
+
+@pytest.mark.parametrize("model_name,batch,nlayers,bits,reg,min_shapes", [("efficientnet_b1", 64, 116, 2, "L1", 50),
+                                                                          ("vgg16", 64, 16, 4, None, 12)])
+def test_configs_3_and_5_through_the_driver(model_name, batch, nlayers, bits, reg, min_shapes, oracle_mod, capsys):
+    """BASELINE.json configs 3 (VGG-16: thirteen convs on up to 90 048-sample rows, fc6 with 25 088 input features) and 5
+    (EfficientNet-B1, sparse GPFQ: reg = 'L1', lambda 0.1, 2 bits) through quantize_network() itself: MBConv blocks --
+    expand 1x1, DEPTHWISE 3x3 / 5x5 with stride 1 / 2 captured on a kernel-strided grid (quantize_neural_net.py:325-350
+    ignores the layer's stride) and quantized group by group (step_algorithm.py:221-247: groups = channels, one row per
+    group), squeeze-excitation 1x1 convs WITH bias on 1x1 maps (m = batch), project 1x1 -- through extract_layers'
+    whitelist (registered block types, utils.py:9-22, :76-93) and the hooks.  Per distinct layer shape the first / last
+    rows (of the first / last group) against the oracle on the inputs the hooks captured; the whole run repeated with the
+    reference's capture op sequence instead of the fused gather: every weight bit-equal."""
+    q, stats = _run(model_name, batch, True, oracle_mod, bits=bits, reg=reg)
+    assert len(q.quantized_network_layers) == nlayers == stats["calls"] == len(q.layer_reports)
+    assert stats["shapes"] >= min_shapes and stats["mismatches"] == 0 and stats["weights"] > 2000, stats
+    K = 2 ** (bits - 1)
+    if model_name == "efficientnet_b1":
+        assert stats["grouped"] >= 12, stats                                   # distinct depthwise shapes met and checked
+        dw = [l for l in q.analog_network_layers if isinstance(l, torch.nn.Conv2d) and l.groups > 1]
+        assert len(dw) == 23 and {(l.kernel_size[0], l.stride[0]) for l in dw} == {(3, 1), (3, 2), (5, 1), (5, 2)}
+    else:
+        assert q.analog_network_layers[13].in_features == 25088
+    nonzero = 0
+    for li, (qa, an, rep) in enumerate(zip(q.quantized_network_layers, q.analog_network_layers, q.layer_reports)):
+        assert rep["timeouts"] == [] and np.isfinite(rep["relative_quantize_error"]) and np.isfinite(rep["quantize_error"])
+        rec = q.layer_indices[li]
+        assert rec["K"] == K and rec["mode"] == (1 if reg == "L1" else 0) and int(rec["idx"].abs().max()) <= K
+        k = qa.weight.detach().reshape(qa.weight.shape[0], -1) / rec["step"]
+        assert torch.equal(torch.round(k).to(torch.int8).cpu(), rec["idx"].to(torch.int8))
+        nonzero += int((rec["idx"] != 0).sum())
+        if qa.bias is not None:
+            assert torch.equal(qa.bias, an.bias)                               # biases are never touched (quantize_neural_net.py:195)
+    assert nonzero > 0
+    out = capsys.readouterr().out
+    assert "Quantizing layer with index: %d" % (nlayers - 1) in out
+    if model_name == "efficientnet_b1":
+        assert "The number of groups: 192" in out or "The number of groups: 1152" in out or "The number of groups: 96" in out
+    q2, _ = _run(model_name, batch, False, bits=bits, reg=reg)
     for a, b in zip(q.quantized_network_layers, q2.quantized_network_layers):
         assert torch.equal(a.weight, b.weight)

@@ -118,3 +118,21 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def test_two_rank_bench_on_one_card_over_gloo_runs_the_whole_multi_rank_script():
+    """`bench.py --gpus 2` end to end (the self-launch under torch.distributed.run, rank set-up, the sharded layers, the events
+    around the all_gather, the max over ranks, the checks on every rank) with both ranks on THIS card and `gloo` for the
+    collectives -- the multi-rank path of the script the driver starts on an 8-GPU node, shape-reduced (--max-cols).  Not a
+    scaling number; RCCL itself runs in test_resnet18_all_layers_sharded_through_rccl_world_of_one."""
+    rec, err = run_bench("--gpus", "2", "--share-gpu", "--backend", "gloo", "--max-cols", "24")
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and "neuron-shard x2" in rec["config"]["parallelism"]
+    assert rec["config"]["layers"] == 16 and rec["config"]["weights"] == sum(N * 24 for N in (64,) * 3 + (128,) * 4 + (256,) * 6 + (512,) * 3)
+    assert [r["rank"] for r in rec["per_rank"]] == [0, 1]
+    for r in rec["per_rank"]:
+        assert r["prep_ms"] > 0 and r["loop_ms"] > 0 and r["collective_ms"] > 0 and r["wall_ms_per_step"] > 0
+    assert rec["collective_ms_per_step"] > 0
+    assert rec["expected"] is not None and "emulated_world2" in rec["expected"]["source"] and rec["expected"]["per_rank_ms_per_step"] > 0
+    oc = rec["output_check"]
+    assert oc["mismatches"] == 0 and oc["ranks"] == 2 and oc["mismatches_all_ranks"] == 0 and oc["weights_all_ranks"] == 2 * oc["weights"]
+    assert rec["oracle_shape_check"]["mismatches"] == 0 and rec["cooperative_timeouts"] == 0
