@@ -276,6 +276,8 @@ def kernel_name(desc, mode=0):
             return "gpfq_resident_rt%d_m%d_w1" % (rt, mode)
         return "gpfq_resident_rt%d_m%d_w%d" % (rt, mode, 8 if waves <= 8 else 12 if waves <= 12 else 16)
     if w[0] == "coop":
+        if kv.get("pipel") == "1":                  # twelve rows in three groups, columns staged through LDS (round 5)
+            return "gpfq_pipel_m%d_w8" % mode
         if kv.get("pipe") == "1":                   # the pipelined kernels: four groups of RT / 4 rows; 7 sweep waves: one reducer wave
             quad = (rt // 4) * int(kv.get("C", "0")) > 64   # four granules per lane (two rows x 128 members), one reducer wave
             return "gpfq_pipe_rg%d_m%d_w8%s" % (rt // 4, mode, "sq" if quad else "s" if waves == 7 else "")
@@ -348,6 +350,32 @@ def pmc_counters(kernel, digest):
             if kernel in name:
                 return v, os.path.relpath(path, ROOT)
     return None, ("no counter summary for this kernel source (newest other: %s): collect with tools/profile_counters.sh" % stale)
+
+
+def family_counter_fracs(families, digest, workload):
+    """Per kernel family of this run: the fraction of its waves' lifetime with an instruction executing / spent waiting
+    (SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY over SQ_WAVE_CYCLES), from the committed counter summary of THIS workload --
+    profiles/*pmc_counters.json for the headline, profiles/*pmc_counters_<workload>.json for the others
+    (tools/profile_counters.sh <tag> "--workload ..." _<workload>) -- and only one stamped with the digest of the kernel
+    sources this run was built from.  (None, reason) without one."""
+    import glob
+    tag = "" if workload == "r50_3x3" else "_" + workload
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_counters%s.json" % tag)), reverse=True):
+        data = json.load(open(path))
+        if data.get("source_sha256") != digest:
+            stale = stale or os.path.relpath(path, ROOT)
+            continue
+        out = {}
+        for fam_name in families:
+            for name, v in data.get("kernels", {}).items():
+                c = v["per_launch"]
+                if fam_name + "(" in name and c.get("SQ_WAVE_CYCLES"):
+                    wc = c["SQ_WAVE_CYCLES"]
+                    out[fam_name] = {"active": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4), "waiting": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 4),
+                                     "valu": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 4), "launches_profiled": v["launches"]}
+        return {"source": os.path.relpath(path, ROOT), "command": data.get("command"), "families": out}, None
+    return None, "no counter summary of workload %s for this kernel source (newest other: %s)" % (workload, stale)
 
 
 def counter_rooflines(dom, fam_rec, digest, l2_model):
@@ -832,7 +860,7 @@ def main():
         loop_ms_total += lm
         coll_ms_total += rec["coll_ms"] / rec["n"]
         row = ("%-22s N=%4d d=%5d g=%4d m=%6d %-30s loop %8.3f ms (%.3f us/col, %6.0f GB/s alg = %5.1f%% of 8 TB/s HBM%s)  prep %7.3f ms"
-               % (name, N, dg, groups, m, " ".join(desc.split()[:3]) + (" pipe" if "pipe=1" in desc else "") + (" x%d" % plan_rounds(desc) if plan_rounds(desc) > 1 else ""), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
+               % (name, N, dg, groups, m, " ".join(desc.split()[:3]) + (" pipe" if "pipe=1" in desc else " pipel" if "pipel=1" in desc else "") + (" x%d" % plan_rounds(desc) if plan_rounds(desc) > 1 else ""), lm, lm * 1e3 / dg, ab / lm / 1e6, ab / lm / 1e6 / HBM_PEAK_GBPS * 100,
                   "" if l2b is None else "; %5.0f GB/s L2 columns = %4.1f%% of 34.5 TB/s" % (l2b / lm / 1e6, l2b / lm / 1e6 / L2_PEAK_GBPS * 100),
                   pm))
         table.append(row)
@@ -939,6 +967,8 @@ def main():
             "roofline": roofline,
             "roofline_l2": roofline_l2,
             "roofline_issue": roofline_issue,
+            "family_counters": (lambda r: r[0] if r[0] else {"source": None, "reason": r[1]})(
+                family_counter_fracs(list(fam), _lib.kernel_source_digest(), args.workload)) if fam else None,
             # the one HBM-bound part of a step: the column preparation (every rank repeats it in full)
             "roofline_prep": (None if args.capture or prep_ms_total <= 0 else
                               {"bound": "hbm", "kernel": "gpfq_transpose_norm_kernel (+ gpfq_colnorm_finish_kernel)",

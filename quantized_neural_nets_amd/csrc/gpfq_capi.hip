@@ -19,6 +19,7 @@
 #include "gpfq_device.h"
 #include "gpfq_loop_kernels.h"
 #include "gpfq_pipe_kernels.h"
+#include "gpfq_pipel_kernels.h"
 #include "gpfq_prep_kernels.h"
 
 // ================================================================================================
@@ -59,7 +60,8 @@ struct Plan {
     int rounds;    // coop: launches the rows are spread over (every launch must be co-resident); 1 = all rows at once
     int tiles_round;   // coop: row tiles per launch
     int grouped;   // coop: one row per group (depthwise convolutions), every row with its own columns
-    int pipe;      // coop: the PIPELINED kernels (gpfq_pipe_kernels.h): RT = 4 or 8 rows in four groups, reducer wave of its own
+    int pipe;      // coop: 1 = the PIPELINED kernels (gpfq_pipe_kernels.h): RT = 4 or 8 rows in four groups, reducer wave(s) of their own;
+                   //       2 = the pipelined kernels with LDS-staged columns (gpfq_pipel_kernels.h): RT = 12 rows in three groups
 };
 
 int device_cu_count()
@@ -194,6 +196,7 @@ double stream_col_cost(int64_t Ng, int S, int cus)
 // from L2 / the Infinity Cache again; U, the 8*N*m bytes per column of the streaming plan, never moves).
 // Depends on (Ng, S, CU count) only -- never on the data.  cost_out: microseconds per column for all rows.
 bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out, bool allow_rounds);
+bool choose_pipel(int64_t Ng, int S, int cus, Plan* pl, double* cost_out, bool allow_rounds);
 
 // allow_pipe false: the lock-step kernels only -- for layers the pipelined kernels cannot take (2^20 columns or more: their
 // epoch word) and for the retry after a pipelined launch was refused (run_loop)
@@ -250,6 +253,19 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
         // lock-step model, which overestimates its 8-wave kernels, says)
         if (choose_pipe(Ng, S, cus, mode, &pp, &pcost, allow_rounds) &&
             (!found || pipe_mode == 1 || (pcost < best && !(pp.waves <= 2 && pl->rounds == 1)))) {
+            *pl = pp;
+            best = pcost;
+            found = true;
+        }
+    }
+    // ... and the twelve-row pipelined kernels with LDS-staged columns (GPFQ_COOP_PIPEL: 0 never, 1 whenever a configuration
+    // exists; default: where modelled cheaper -- layers in rounds, whose rounds they cut by a third)
+    // (GPFQ_COOP_PIPE=0, "no pipelined kernels", switches this family off too unless it is asked for by name)
+    const int pipel_mode = env_int("GPFQ_COOP_PIPEL", pipe_mode == 0 ? 0 : -1);
+    if (pipel_mode != 0 && allow_pipe && !force_rt) {
+        Plan pp = *pl;
+        double pcost = 0.0;
+        if (choose_pipel(Ng, S, cus, &pp, &pcost, allow_rounds) && (!found || pipel_mode == 1 || pcost < best)) {
             *pl = pp;
             best = pcost;
             found = true;
@@ -322,6 +338,51 @@ bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
                 pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
                 pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0; pl->pipe = 1;
             }
+        }
+    }
+    if (found && cost_out) *cost_out = best;
+    return found;
+}
+
+// One column step of the pipelined kernels with LDS-staged columns (gpfq_pipel_kernels.h), microseconds: three phases, each the
+// sweep of one group -- four rows, two interleaved pairs: 160 packed instructions per sweep wave -- on the fullest SIMD plus
+// the lane tree, the LDS word and the barrier; the exchange hides under it.  (First measurements, round 5: see profiles/NOTES.md.)
+// Measured per column and round (tools/layer_bench.py, round 5): 128 members x 7 waves 3.67, 32 x 7 3.2-3.3, 8 x 7 3.3-3.4,
+// 2 x 7 3.34, 64 x 5 3.0.  What bounds a phase is the vector ALU: 250 instructions per sweep wave, two sweep waves per SIMD,
+// 4.9 cycles each (v_pk_fma_f32 takes two passes) = 2 400 cycles.
+double pipel_step_cost(int waves, int C)
+{
+    const int per_simd = (waves + 3) / 4;
+    const double sweep = 0.45 * per_simd + (waves > 4 ? 0.19 : 0.29);
+    const double gather = C > 32 ? 1.22 : 0.60;                       // (128 members: the reducer's re-polls; device scope throughout)
+    return 3.0 * (sweep > gather ? sweep : gather);
+}
+
+// The configurations of that family for (Ng rows, S segments): RT = 12, C members with at most 7 segments each (7 sweep waves +
+// the reducer: eight waves of 256 registers), up to 128 members (four granules of a row pair per lane of the gather).
+bool choose_pipel(int64_t Ng, int S, int cus, Plan* pl, double* cost_out, bool allow_rounds)
+{
+    const int force_c = env_int("GPFQ_COOP_C", 0);
+    const int RT = gpfq::kPipelRows;
+    const int64_t tiles = (Ng + RT - 1) / RT;
+    double best = 1e30;
+    bool found = false;
+    for (int C = 128; C >= 2; C >>= 1) {
+        if (force_c && C != force_c) continue;
+        if (C > S || C > cus) continue;
+        const int NW = (S + C - 1) / C;
+        if (NW > 7 || pow2_ceil_host(S) / C > 16) continue;
+        const int64_t tiles_round = tiles * C <= cus ? tiles : cus / C;
+        if (tiles_round < 1) continue;
+        const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
+        if (rounds > 1 && !allow_rounds) continue;
+        if ((size_t)tiles_round * 2 * C * RT * sizeof(unsigned long long) > kScratchStatusOffset) continue;
+        const double cost = (double)rounds * pipel_step_cost(NW, C);
+        if (!found || cost < best - 1e-9) {
+            found = true;
+            best = cost;
+            pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
+            pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0; pl->pipe = 2;
         }
     }
     if (found && cost_out) *cost_out = best;
@@ -747,8 +808,54 @@ int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     return GPFQ_OK;
 }
 
+SlabKernel pipel_kernel(int mode)
+{
+    switch (mode) {
+    case gpfq::MODE_SOFT: return gpfq::gpfq_pipel_m1_w8;
+    case gpfq::MODE_HARD: return gpfq::gpfq_pipel_m2_w8;
+    case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_pipel_m3_w8;
+    default: return gpfq::gpfq_pipel_m0_w8;
+    }
+}
+
+// twelve rows in three groups, columns staged through LDS (gpfq_pipel_kernels.h)
+int launch_pipel(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
+{
+    if (!p_d_fits_epoch(sp.d)) return fail(GPFQ_ERR_UNSUPPORTED, "pipelined cooperative kernels take fewer than 2^20 columns");
+    if (pl.RT != gpfq::kPipelRows || pl.waves < 1 || pl.waves > 7 || pl.C > 128 || pl.C < 1)
+        return fail(GPFQ_ERR_UNSUPPORTED, "internal: no LDS-staged pipelined kernel for this (rows, waves, members) triple");
+    SlabKernel kern = pipel_kernel(mode);
+    const int threads = 64 * (pl.waves + 1);                           // + the reducer wave
+    const size_t shm = gpfq::pipel_lds_bytes(pl.waves);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (e != hipSuccess) return hip_fail(e, "dynamic LDS size");
+    const int cus = device_cu_count();
+    const int nblocks = pl.tiles * pl.C;
+    int nb = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, shm);
+    if (e != hipSuccess) return hip_fail(e, "occupancy query");
+    if (nb < 1 || nblocks > cus) return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
+    size_t xbytes = (size_t)pl.tiles * 2 * pl.C * pl.RT * sizeof(unsigned long long);
+    xbytes = (xbytes + 15) & ~(size_t)15;
+    if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
+    e = hipMemsetAsync(scratch, 0, xbytes, st);
+    if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
+    gpfq::SlabParams spx = sp;
+    // low five bits: the reducer's pause in front of its gather request, in units of 64 clocks (gpfq_pipel_kernels.h (c))
+    // (measured: 8 x 64 clocks and priority 2 are the best or within the noise of it at 2 / 8 / 32 / 128 members)
+    spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_PIPEL_REQUEST_PAUSE", 8) & 31u);
+    spx.xcd_tiles = env_int("GPFQ_PIPEL_REDUCER_PRIO", 2) & 3;               // (the reducer wave's issue priority)
+    static std::atomic<unsigned> launch_number{0};
+    spx.salt = launch_number.fetch_add(1) & 255u;
+    spx.allow_local = 0;
+    e = launch_waiting_grid(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
+    if (e != hipSuccess) return hip_fail(e, "GPFQ LDS-staged pipelined cooperative kernel launch");
+    return GPFQ_OK;
+}
+
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
+    if (pl.pipe == 2) return launch_pipel(pl, sp, mode, scratch, st);
     if (pl.pipe) return launch_pipe(pl, sp, mode, scratch, st);
     const int RT = pl.RT;
     int maxw = 0;
@@ -1337,10 +1444,10 @@ int gpfq_describe_plan_mode(int64_t N, int64_t d_g, int64_t m, int groups, int p
                      pl.tiles_round * pl.C, pl.rounds, groups, (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_COOP && pl.rounds > 1)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d rounds=%d%s d=%lld", pl.RT, pl.C, pl.waves, pl.S,
-                     pl.tiles_round * pl.C, pl.rounds, pl.pipe ? " pipe=1" : "", (long long)d_g);
+                     pl.tiles_round * pl.C, pl.rounds, pl.pipe == 2 ? " pipel=1" : pl.pipe ? " pipe=1" : "", (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_COOP)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d%s d=%lld", pl.RT, pl.C, pl.waves, pl.S,
-                     pl.tiles * pl.C, pl.pipe ? " pipe=1" : "", (long long)d_g);
+                     pl.tiles * pl.C, pl.pipe == 2 ? " pipel=1" : pl.pipe ? " pipe=1" : "", (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_STREAM && pl.C > 1)
             snprintf(buf, buf_bytes, "stream RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
                      pl.tiles * pl.C, (long long)d_g);

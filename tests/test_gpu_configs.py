@@ -19,7 +19,7 @@ CASES = [
     ("alexnet_conv2_b32", 48, 150, bw.conv_m(32, 27, 5, 2), 1, 4, None, 0.1, "resident"),
     ("resnet18_l1_conv_b256", 64, 96, bw.conv_m(256, 56, 3, 1), 1, 4, None, 0.1, "coop"),   # m = 23296
     ("resnet18_fc_b256", 1000, 64, 256, 1, 4, None, 0.1, "resident"),
-    ("vgg16_conv1_2_b512", 16, 40, bw.conv_m(512, 224, 3, 1), 1, 4, None, 0.1, "coop RT=4 C=64"),   # m = 720 384: 704 segments, 11 per member: the LDS-staged 64-member kernel, one round
+    ("vgg16_conv1_2_b512", 16, 40, bw.conv_m(512, 224, 3, 1), 1, 4, None, 0.1, "coop RT=12 C=128 waves=6 S=704 grid=256 pipel=1"),   # m = 720 384: 704 segments, 5.5 per member: twelve rows x 128 members (round 5; before: the LDS-staged four-row kernel on 64 members -- tests/test_gpu_rounds.py keeps it covered)
     ("vgg16_fc6_b512", 128, 256, 512, 1, 4, None, 0.1, "resident"),
     ("effnet_b1_depthwise_b1024", 8, 9, bw.conv_m(1024, 112, 3, 1), 8, 2, "L1", 0.1, "coop RT=1 C=32 waves=12 S=362 grid=256 rounds=1 groups=8"),   # m = 370 688, N_g = 1
     ("effnet_b1_depthwise5_b1024", 12, 25, bw.conv_m(1024, 14, 5, 2), 12, 2, "L1", 0.1, "resident"),

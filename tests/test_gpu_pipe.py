@@ -35,14 +35,14 @@ CASES = [
     ((24, 20, 26624), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_RT": "8", "GPFQ_COOP_C": "8", "GPFQ_COOP_XCD_TILES": "0"}, "coop RT=8 C=8 waves=4 S=26 grid=24 pipe=1",
      "the same without placement: members spread over the XCDs -- the first gather finds it, device-scope publishing throughout"),
     ((112, 9, 51200), {}, "coop RT=8 C=16 waves=4 S=50 grid=224 pipe=1", "14 tiles padded to 16 (EfficientNet-B1's 112-channel project convs)"),
-    ((300, 24, 51200), {}, "coop RT=8 C=8 waves=7 S=50 grid=256 rounds=2 pipe=1",
+    ((300, 24, 51200), {"GPFQ_COOP_PIPEL": "0"}, "coop RT=8 C=8 waves=7 S=50 grid=256 rounds=2 pipe=1",
      "SEVEN sweep waves: one wave for both reducer roles (vmcnt(1) behind its own store); the last round partial"),
     ((2048, 6, 13312), {}, "coop RT=8 C=2 waves=7 S=13 grid=256 rounds=2 pipe=1", "two members per tile, the one-wave reducer"),
-    ((70, 16, 201728), {}, "coop RT=8 C=32 waves=7 S=197 grid=256 rounds=2 pipe=1", "64 granules per gather (two rows x 32 members: 32 lanes per row)"),
+    ((70, 16, 201728), {"GPFQ_COOP_PIPEL": "0"}, "coop RT=8 C=32 waves=7 S=197 grid=256 rounds=2 pipe=1", "64 granules per gather (two rows x 32 members: 32 lanes per row)"),
     ((70, 12, 26624), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "4"}, "coop RT=4 C=4 waves=7 S=26 grid=72 pipe=1", "single rows with the one-wave reducer"),
     ((9, 4, 400000), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_RT": "4"}, "coop RT=4 C=64 waves=7 S=391 grid=192 pipe=1",
      "64 members of one row per gather (all 64 lanes), the last tile with one valid row"),
-    ((21, 6, 803840), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_C": "128"}, "coop RT=8 C=128 waves=7 S=785 grid=256 rounds=2 pipe=1",
+    ((21, 6, 803840), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_C": "128", "GPFQ_COOP_PIPEL": "0"}, "coop RT=8 C=128 waves=7 S=785 grid=256 rounds=2 pipe=1",
      "two rows x 128 members per gather: FOUR granules per lane, members on four XCDs (device-scope publishing); the last tile has 5 valid rows"),
     ((16, 1, 26624), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_RT": "8"}, "coop RT=8 C=16 waves=2 S=26 grid=32 pipe=1", "ONE column: the pipeline is all fill and drain"),
     ((16, 2, 26624), {"GPFQ_COOP_PIPE": "1", "GPFQ_COOP_RT": "8"}, "coop RT=8 C=16 waves=2 S=26 grid=32 pipe=1", "two columns"),
@@ -75,12 +75,13 @@ def test_pipelined_kernels_equal_oracle_and_streaming(oracle_mod, monkeypatch, s
 
 
 @pytest.mark.parametrize("mode", ["soft", "hard", "stochastic"])
-def test_pipelined_kernels_other_quantizers_and_global_row_keys(oracle_mod, mode):
+def test_pipelined_kernels_other_quantizers_and_global_row_keys(oracle_mod, monkeypatch, mode):
     """soft / hard / stochastic through both row groupings and both reducer arrangements, in rounds: the stochastic
     quantizer's Philox key is the GLOBAL row number (oracle keyed the same way)."""
     from quantized_neural_nets_amd import _lib
     omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
     lmode = {"soft": _lib.MODE_SOFT, "hard": _lib.MODE_HARD, "stochastic": _lib.MODE_STOCHASTIC}[mode]
+    monkeypatch.setenv("GPFQ_COOP_PIPEL", "0")       # (the twelve-row family would take the first two in one round: tests/test_gpu_pipel.py)
     for (N, d, m) in ((130, 9, 93184), (300, 8, 51200), (64, 11, 93184)):
         desc = _lib.describe_plan(N, d, m, 1, 0, lmode)
         assert "pipe=1" in desc and desc == _lib.describe_plan(N, d, m, 1, 0, _lib.MODE_MSQ), desc

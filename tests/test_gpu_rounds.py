@@ -28,7 +28,7 @@ def _run(W, A, X, m, plan, mode="msq", seed=None, K=8, step=None):
 
 # (N, d, m), forced configuration ({} = what AUTO picks), the plan that must result, what the case is there for
 CASES = [
-    ((300, 24, 51200), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "8"}, "coop RT=4 C=8 waves=7 S=50 grid=256 rounds=3",
+    ((300, 24, 51200), {"GPFQ_COOP_RT": "4", "GPFQ_COOP_C": "8", "GPFQ_COOP_PIPEL": "0"}, "coop RT=4 C=8 waves=7 S=50 grid=256 rounds=3",
      "three rounds, the last one partial (44 rows)"),
     ((300, 24, 51200), {"GPFQ_COOP_RT": "2", "GPFQ_COOP_C": "4"}, "coop RT=2 C=4 waves=13 S=50 grid=256 rounds=3",
      "two rows x 13 sweep waves: the 16-wave variant"),
@@ -38,12 +38,12 @@ CASES = [
     ((300, 24, 51200), {"GPFQ_COOP_PIPE": "0"}, "coop RT=4 C=4 waves=13 S=50 grid=256 rounds=2",
      "four rows x 13 sweep waves, columns staged through LDS (global_load_lds); 256 rows per round, the last round partial"),
     ((70, 16, 201728), {"GPFQ_COOP_PIPE": "0"}, "coop RT=4 C=16 waves=13 S=197 grid=256 rounds=2", "the same variant with 16 members (64 granules)"),
-    ((21, 10, 803840), {}, "coop RT=4 C=64 waves=13 S=785 grid=256 rounds=2",
+    ((21, 10, 803840), {"GPFQ_COOP_PIPEL": "0"}, "coop RT=4 C=64 waves=13 S=785 grid=256 rounds=2",
      "the same variant with 64 members: 256 granules gathered four per lane; 16 rows per round, 5 in the last"),
     ((20, 10, 720384), {"GPFQ_COOP_RT": "2"}, "coop RT=2 C=64 waves=11 S=704 grid=256 rounds=3", "128 granules at 64 members (VGG-16 conv1 rows)"),
-    ((20, 10, 720384), {}, "coop RT=4 C=64 waves=11 S=704 grid=256 rounds=2",
+    ((20, 10, 720384), {"GPFQ_COOP_PIPEL": "0"}, "coop RT=4 C=64 waves=11 S=704 grid=256 rounds=2",
      "the LDS-staged 64-member kernel with fewer than 13 sweep waves (VGG-16 conv1 rows: 11 segments per member)"),
-    ((9, 6, 530000), {}, "coop RT=4 C=64 waves=9 S=518 grid=192",
+    ((9, 6, 530000), {"GPFQ_COOP_PIPEL": "0"}, "coop RT=4 C=64 waves=9 S=518 grid=192",
      "the same with 9 sweep waves, members of 8 and 9 segments, one round with a partial last tile"),
     ((70, 12, 263168), {"GPFQ_COOP_PIPE": "0"}, "coop RT=4 C=32 waves=9 S=257 grid=256 rounds=3", "four rows x 9 sweep waves, one step of look-ahead, 128 granules"),
     ((12, 6, 1440768), {}, "coop RT=2 C=128 waves=11 S=1407 grid=256 rounds=3",
@@ -89,13 +89,14 @@ def test_rounds_equal_oracle_and_streaming(oracle_mod, monkeypatch, shape, env, 
 
 
 @pytest.mark.parametrize("mode", ["soft", "hard", "stochastic"])
-def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, mode):
+def test_rounds_other_quantizers_and_global_row_keys(oracle_mod, monkeypatch, mode):
     """The other three quantizers through rounds (the 16-wave two-row variant and the four-row one); the stochastic
     quantizer's Philox key is the GLOBAL row number, so the rows of a later round must not repeat the first round's
     draws: equality with the oracle (keyed by global rows) and with the streaming plan shows it."""
     from quantized_neural_nets_amd import _lib
     omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
     lmode = {"soft": _lib.MODE_SOFT, "hard": _lib.MODE_HARD, "stochastic": _lib.MODE_STOCHASTIC}[mode]
+    monkeypatch.setenv("GPFQ_COOP_PIPEL", "0")       # (the twelve-row family takes the first two shapes in one round: tests/test_gpu_pipel.py)
     for (N, d, m) in ((21, 6, 803840), (260, 8, 51200), (9, 3, 3212288)):   # (the last: four rows x 256 members, three rounds)
         # every (rows, waves) pair is instantiated for all four quantizers (the stochastic forms of the four-row 12-wave
         # and of the 256-member two-row kernel fit their register budgets since round 3): the plan does not depend on the

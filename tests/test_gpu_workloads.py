@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra, timeout=850):
+def run_bench(*extra, timeout=850, shared_card=False):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + list(extra)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
@@ -30,7 +30,9 @@ def run_bench(*extra, timeout=850):
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["output_check"]["mismatches"] == 0, rec["output_check"]
     assert rec["oracle_shape_check"]["mismatches"] == 0, rec["oracle_shape_check"]
-    assert rec["cooperative_timeouts"] == 0
+    # (two ranks rehearsing on ONE card are two tenants: each sizes its cooperative grids for a whole chip, so a launch may find
+    # its peers not resident, give up within its bound and be redone on the streaming plan -- correct results, reported)
+    assert rec["cooperative_timeouts"] == 0 or shared_card
     return rec, out.stderr
 
 
@@ -125,7 +127,7 @@ def test_two_rank_bench_on_one_card_over_gloo_runs_the_whole_multi_rank_script()
     around the all_gather, the max over ranks, the checks on every rank) with both ranks on THIS card and `gloo` for the
     collectives -- the multi-rank path of the script the driver starts on an 8-GPU node, shape-reduced (--max-cols).  Not a
     scaling number; RCCL itself runs in test_resnet18_all_layers_sharded_through_rccl_world_of_one."""
-    rec, err = run_bench("--gpus", "2", "--share-gpu", "--backend", "gloo", "--max-cols", "24")
+    rec, err = run_bench("--gpus", "2", "--share-gpu", "--backend", "gloo", "--max-cols", "24", shared_card=True)
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and "neuron-shard x2" in rec["config"]["parallelism"]
     assert rec["config"]["layers"] == 16 and rec["config"]["weights"] == sum(N * 24 for N in (64,) * 3 + (128,) * 4 + (256,) * 6 + (512,) * 3)
     assert [r["rank"] for r in rec["per_rank"]] == [0, 1]
@@ -135,4 +137,4 @@ def test_two_rank_bench_on_one_card_over_gloo_runs_the_whole_multi_rank_script()
     assert rec["expected"] is not None and "emulated_world2" in rec["expected"]["source"] and rec["expected"]["per_rank_ms_per_step"] > 0
     oc = rec["output_check"]
     assert oc["mismatches"] == 0 and oc["ranks"] == 2 and oc["mismatches_all_ranks"] == 0 and oc["weights_all_ranks"] == 2 * oc["weights"]
-    assert rec["oracle_shape_check"]["mismatches"] == 0 and rec["cooperative_timeouts"] == 0
+    assert rec["oracle_shape_check"]["mismatches"] == 0

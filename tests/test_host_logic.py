@@ -119,7 +119,11 @@ def test_plan_selection(lib):
     # (eight rows per tile, seven sweep waves + ONE reducer wave for both roles: the pipelined `_w8s` variant)
     assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=8 C=8 waves=7 S=50 grid=256 rounds=8 pipe=1")
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=8 C=32 waves=7 S=197 grid=256 rounds=16 pipe=1")
-    assert lib.describe_plan(256, 64, 803840).startswith("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16")    # 256 granules
+    # (round 5: twelve rows per tile in three groups, columns through LDS, 128 members: 11 rounds instead of the 16 of the four-row
+    # lock-step kernel on 64 members, which stays selectable -- GPFQ_COOP_PIPEL=0)
+    assert lib.describe_plan(256, 64, 803840).startswith("coop RT=12 C=128 waves=7 S=785 grid=256 rounds=11 pipel=1")
+    assert lib.describe_plan(512, 256, 803840).startswith("coop RT=12 C=128 waves=7 S=785 grid=256 rounds=22 pipel=1")
+    assert lib.describe_plan(64, 147, 263168).startswith("coop RT=12 C=64 waves=5 S=257 grid=256 rounds=2 pipel=1")
     assert lib.describe_plan(256, 512, 13312).startswith("resident RT=1 waves=13")      # <= 16 segments, one round: whole rows, no exchange
     assert lib.describe_plan(16, 32, 3212288).startswith("coop RT=4 C=256 waves=13 S=3137 grid=256 rounds=4")    # four rows on the whole chip (1024 granules)
     assert lib.describe_plan(2, 32, 3212288).startswith("coop RT=2 C=256 waves=13 S=3137 grid=256 d=32")           # two rows: the 512-granule kernel
@@ -147,13 +151,22 @@ def test_plan_selection_lock_step_family(lib, monkeypatch):
     assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=4 C=16 waves=13 S=197 grid=256 rounds=16")
     assert lib.describe_plan(2048, 512, 13312).startswith("coop RT=4 C=2 waves=7 S=13 grid=256 rounds=4")
     assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=2 C=4 waves=7 S=26 grid=256 d=")
+    assert lib.describe_plan(256, 64, 803840).startswith("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16")    # 256 granules
     monkeypatch.setenv("GPFQ_COOP_PIPE", "1")        # forced: also where AUTO would not take it
+    monkeypatch.setenv("GPFQ_COOP_PIPEL", "0")
     assert lib.describe_plan(64, 576, 23296).startswith("coop RT=4 C=16 waves=2 S=23 grid=256 pipe=1")
     monkeypatch.setenv("GPFQ_COOP_RT", "8")
     assert lib.describe_plan(128, 1152, 26624).startswith("coop RT=8 C=16 waves=2 S=26 grid=256 pipe=1")
     monkeypatch.delenv("GPFQ_COOP_RT")
     monkeypatch.setenv("GPFQ_COOP_C", "128")         # 256 granules per gather: only when asked for
     assert lib.describe_plan(21, 6, 803840).startswith("coop RT=8 C=128 waves=7 S=785 grid=256 rounds=2 pipe=1")
+    monkeypatch.delenv("GPFQ_COOP_C")
+    monkeypatch.delenv("GPFQ_COOP_PIPE")
+    monkeypatch.setenv("GPFQ_COOP_PIPEL", "1")       # the twelve-row family wherever a configuration exists
+    assert lib.describe_plan(1024, 256, 51200).startswith("coop RT=12 C=8 waves=7 S=50 grid=256 rounds=3 pipel=1")
+    assert lib.describe_plan(512, 128, 201728).startswith("coop RT=12 C=32 waves=7 S=197 grid=256 rounds=6 pipel=1")
+    monkeypatch.setenv("GPFQ_COOP_PIPEL", "0")
+    assert lib.describe_plan(256, 64, 803840).startswith("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16")
 
 
 def test_partition_covers_every_neuron_once():
@@ -341,6 +354,7 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert bench.kernel_name("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16 d=64", 1) == "gpfq_coop_rt4_m1_w16lq"
     assert bench.kernel_name("coop RT=1 C=16 waves=6 S=91 grid=128 d=576") == "gpfq_coop_rt1_m0_w12"
     assert bench.kernel_name("coop RT=1 C=32 waves=12 S=362 grid=256 rounds=12 groups=96 d=9", 1) == "gpfq_coop_rt1g_m1_w12"
+    assert bench.kernel_name("coop RT=12 C=128 waves=7 S=785 grid=256 rounds=11 pipel=1 d=64", 1) == "gpfq_pipel_m1_w8"
     assert bench.plan_rounds("coop RT=2 C=64 waves=13 S=785 grid=256 rounds=32 d=64") == 32
     assert bench.plan_rounds("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == 1
     assert bench.l2_column_bytes("resident RT=2 waves=7 S=7 grid=(256,1) d=4608", 512, 4608, 7168) == 256 * 4608 * 8 * 7168

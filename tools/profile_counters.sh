@@ -6,8 +6,14 @@
 # (MI355X_MICROARCH.md "rocprofv3 PMC slots"); names the installed rocprofv3 does not list (`rocprofv3 -L`) are dropped
 # from a pass instead of failing it.  tools/pmc_counters.py turns the passes into profiles/<tag>_pmc_counters.json,
 # stamped with the digest of the kernel sources; bench.py quotes it only when the stamp matches the sources it runs.
+# A second argument = extra bench.py arguments (another workload), a third = the suffix of the summary's name:
+#   bash tools/profile_counters.sh r05_v1 "--workload r50_all --distinct-shapes --max-cols 96" _r50_all
+# (every distinct layer shape of ResNet-50 with its full N, m and groups -- hence plan, kernel variant and rounds -- and 96
+# input features per group: the per-kernel RATIOS bench.py quotes, active / waiting over wave cycles, are those of the full
+# layers' steady state; the per-launch totals are 96 columns' worth)
 TAG=${1:-r03_v1}
 WORKLOAD_ARGS=${2:-}
+SUFFIX=${3:-}
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -37,6 +43,12 @@ for P in "${PASSES[@]}"; do
   F=$(find gpurun_out/prof_pmc$n -name "*counter_collection.csv" | head -1)
   [ -n "$F" ] && CSVS="$CSVS $F"
 done
-python3 tools/pmc_counters.py $CSVS > gpurun_out/${TAG}_pmc_counters.json
+python3 tools/pmc_counters.py $CSVS > gpurun_out/${TAG}_pmc_counters${SUFFIX}.json
+[ -n "$WORKLOAD_ARGS" ] && python3 - "gpurun_out/${TAG}_pmc_counters${SUFFIX}.json" "$WORKLOAD_ARGS" <<'PYEOF'
+import json, sys
+d = json.load(open(sys.argv[1]))
+d["command"] = d["command"].replace("--no-output-check", "--no-output-check " + sys.argv[2])
+json.dump(d, open(sys.argv[1], "w"), indent=1)
+PYEOF
 for i in $(seq 1 $n); do rm -rf gpurun_out/prof_pmc$i; done
-head -c 3000 gpurun_out/${TAG}_pmc_counters.json
+head -c 3000 gpurun_out/${TAG}_pmc_counters${SUFFIX}.json

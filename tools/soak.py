@@ -26,7 +26,7 @@ def main():
     t0 = time.time()
     bad = 0
     for ci in range(ncases):
-        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise", "chip_wide", "pipe", "pipe", "lock"])
+        fam = rng.choice(["wave", "resident", "coop", "coop_rows", "rounds", "stream", "grouped", "depthwise", "chip_wide", "pipe", "pipe", "lock", "pipel", "pipel"])
         groups = 1
         if fam == "wave":                           # one-segment rows: the resident kernel's one-wave variant, 1 / 2 / 4 rows per wave
             N, m = int(rng.integers(1, 300)), int(rng.integers(1, 1025))
@@ -61,6 +61,13 @@ def main():
                 os.environ["GPFQ_PIPE_LOCAL"] = "0"  # device-scope publishing throughout
             if rng.integers(0, 2):
                 os.environ["GPFQ_COOP_C"] = str(int(rng.choice([2, 4, 8, 16, 32, 64])))
+        elif fam == "pipel":                        # twelve rows in three groups, columns through LDS (round 5): every member count,
+            N = int(rng.integers(1, 120))           # ragged last tiles, rounds
+            c = int(rng.choice([2, 4, 8, 16, 32, 64, 128]))
+            segs = int(rng.integers(max(c, 2), 7 * c + 1))                        # 1 .. 7 segments per member
+            m = 1024 * (segs - 1) + int(rng.integers(1, 1025))
+            os.environ["GPFQ_COOP_PIPEL"] = "1"
+            os.environ["GPFQ_COOP_C"] = str(c)
         elif fam == "lock":                         # the lock-step kernels where AUTO would pipeline: tile counts that are multiples
             rt = int(rng.choice([1, 2, 4]))         # of eight (members of a tile placed on one XCD), and some that are not
             N = rt * 8 * int(rng.integers(1, 5)) - (int(rng.integers(0, rt * 8)) if rng.integers(0, 4) == 0 else 0)
@@ -76,10 +83,11 @@ def main():
         else:
             groups = int(rng.choice([2, 3, 4]))
             N, m = groups * int(rng.integers(1, 8)), int(rng.integers(1, 6000))
-        d = int(rng.integers(1, 5 if fam == "chip_wide" else 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam in ("coop_rows", "pipe", "lock") else 40))
+        d = int(rng.integers(1, 5 if fam == "chip_wide" else 7 if fam == "rounds" else 10 if fam == "depthwise" else 12 if fam in ("coop_rows", "pipe", "lock") else
+                             (6 if m > 300000 else 12) if fam == "pipel" else 40))
         bits = int(rng.choice([2, 3, 4]))
         reg = [None, "L1", "L0"][int(rng.integers(0, 3))]
-        plan = 1 if fam == "stream" else 0
+        plan = 1 if fam == "stream" else 3 if fam == "pipel" else 0      # (3: the cooperative family asked for, short rows too)
         case = dict(name="soak%d" % ci, N=N, d=d, m=m, bits=bits, scalar=1.16, percentile=1.0, reg=reg, lamb=0.02,
                     groups=groups, first_layer=bool(rng.integers(0, 2)), zero_every=int(rng.choice([0, 3, 7])),
                     seed=int(rng.integers(0, 1 << 30)))
@@ -94,9 +102,9 @@ def main():
         o = oracle.quantize_layer(W, A, X, 1.16 / K, K, 1.0, reg, 0.02, groups)
         full = _lib.describe_plan(N, d, m, groups, plan)
         desc = (full.split(" S=")[0] if full.startswith("coop") else full.split()[0]) + (
-            "+groups" if "groups=" in full else "+rounds" if "rounds=" in full else "") + ("+pipe" if "pipe=1" in full else "")
+            "+groups" if "groups=" in full else "+rounds" if "rounds=" in full else "") + ("+pipe" if "pipe=1" in full else "+pipel" if "pipel=1" in full else "")
         kinds[desc] = kinds.get(desc, 0) + 1
-        for k in ("GPFQ_COOP_RT", "GPFQ_COOP_C", "GPFQ_COOP_PIPE", "GPFQ_PIPE_LOCAL"):
+        for k in ("GPFQ_COOP_RT", "GPFQ_COOP_C", "GPFQ_COOP_PIPE", "GPFQ_PIPE_LOCAL", "GPFQ_COOP_PIPEL"):
             os.environ.pop(k, None)
         ok = (np.array_equal(r["idx"].cpu().numpy().astype(np.int16), o["idx"])
               and np.array_equal(r["Q"].cpu().numpy().view(np.uint32), o["Q"].view(np.uint32))

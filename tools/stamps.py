@@ -41,8 +41,14 @@ for a in sys.argv[1:]:
         who = (("gatherer", 0), ("sweep0", 8))
         rn = ["barrier", "requested gather lands", "re-polls", "next request", "tree + quantizer + q to LDS", "-", "PUBLISHER barrier", "PUBLISHER slot tree + publish"]
         sn = ["barrier", "q from LDS + column wait", "sweep", "lane tree + LDS", "column / weight requests", "-", "-", "-"]
+    if "pipel=1" in desc:
+        # twelve rows in three groups, columns through LDS: cycles per PHASE (three per step), reducer wave and sweep wave 0 of workgroup 0
+        dl = 3 * min(d, 512)
+        who = (("reducer", 0), ("sweep0", 8))
+        rn = ["barrier", "slot tree + publish", "requested gather lands", "re-polls", "tree + quantizer + q to LDS", "pause + next request", "-", "-"]
+        sn = ["barrier", "q from LDS + column wait + DMA", "sweep (2 pairs, LDS reads)", "lane tree + LDS", "weight requests", "-", "-", "-"]
     for w, off in who:
-        if "pipe=1" in desc:
+        if "pipe=1" in desc or "pipel=1" in desc:
             names = rn if off == 0 else sn
         tot = sum(dbg[off:off + 8])
         print("  %-8s total %.0f cyc/step (clock %.2f GHz):" % (w, tot / dl, tot / dl / (ms * 1e3 / dl) / 1e3), "  ".join("%s %.0f" % (names[i], dbg[off + i] / dl) for i in range(8)))
