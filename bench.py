@@ -294,6 +294,81 @@ def kernel_name(desc, mode=0):
     return "gpfq_stream_kernel<%d, true" % rt
 
 
+# ---- the bounded whole-job roofline (round 5) ------------------------------------------------------------------------
+# Every kernel family is held against the roof that binds IT -- a floor on its time that no re-arrangement of the same work on
+# this chip can go below -- and the job's fraction is sum(floors) / sum(measured times): <= 1 by construction, one number for
+# the whole step.  The terms and where each comes from (all under profiles/ or the hardware guide):
+#   vector ALU   a packed fp32 instruction occupies a SIMD for 4.45 cycles with two waves on it, and one wave issues an
+#                instruction every 5.2 cycles at best (profiles/r05_probe_valu.txt); the sweep of a row PAIR over one segment
+#                is 80 packed instructions, of a single row 48 -- the reference's five individually rounded operations per
+#                element (step_algorithm.py:141-148) allow no fewer;
+#   vector L1    a CU takes 64 B per clock from L2 (34.5 TB/s over the chip, MI355X_MICROARCH.md): the columns a resident
+#                workgroup pulls, 8 * m_pad bytes per row tile per step;
+#   exchange     a publish -> gather between workgroups costs >= 0.65 us with every sweep wave idle in the lock-step kernels
+#                (profiles/r03_xchg_probe.txt, profiles/r02_xchg_probe.txt); the pipelined kernels hide it;
+#   HBM          8 TB/s: the streaming kernels' algorithmic bytes and the column preparation's.
+ROOF_CLOCK_HZ = 2.4e9               # MI355X_MICROARCH.md: max clock -- a roof is what the hardware could do
+ROOF_PK_SIMD_CYCLES = 4.45          # profiles/r05_probe_valu.txt
+ROOF_WAVE_ISSUE_CYCLES = 5.2        # profiles/r05_probe_valu.txt
+ROOF_EXCHANGE_US = 0.65             # profiles/r03_xchg_probe.txt
+
+
+def roof_floor_ms(desc, dg, groups, ab, l2b):
+    """(roof name, floor in ms) of ONE launch sequence of a layer's loop under plan `desc` (all rounds, all d columns)."""
+    w = desc.split()
+    kv = dict(x.split("=") for x in w[1:] if "=" in x)
+    if w[0] == "stream":
+        return "hbm", ab / (HBM_PEAK_GBPS * 1e9) * 1e3
+    rt, waves, rounds = int(kv["RT"]), int(kv["waves"]), int(kv.get("rounds", "1"))
+    per_simd = max(1, -(-waves // 4))
+    cyc_per_inst = max(ROOF_WAVE_ISSUE_CYCLES, ROOF_PK_SIMD_CYCLES * per_simd)      # per instruction of ONE wave's stream
+    us = lambda insts: insts * cyc_per_inst / ROOF_CLOCK_HZ * 1e6                      # noqa: E731
+    pair_or_single = lambda rows: 48 if rows == 1 else 80 * (rows // 2)                # noqa: E731
+    if w[0] == "resident":
+        l1 = l2b / (L2_PEAK_GBPS * 1e9) * 1e3 if l2b is not None else 0.0
+        if int(kv.get("S", "0")) == 1:
+            return "vector L1", l1
+        valu = dg * us(pair_or_single(rt)) * 1e-3
+        return ("vector L1", l1) if l1 >= valu else ("vector ALU", valu)
+    steps = dg * rounds * (1 if "groups" not in kv else 1)
+    if kv.get("pipel") == "1":
+        return "vector ALU", steps * 3 * us(160) * 1e-3
+    if kv.get("pipe") == "1":
+        return "vector ALU", steps * 4 * us(pair_or_single(rt // 4)) * 1e-3
+    return "vector ALU + exchange", steps * (us(pair_or_single(rt)) + ROOF_EXCHANGE_US) * 1e-3
+
+
+def roofline_bound(fam, prep_ms_per_step, prep_bytes_per_step, steps, capture):
+    """One bounded fraction for the whole step: sum over the kernel families (and the column preparation) of the floor their
+    binding roof sets / the time they took.  fam[...]["ms"] and ["floor_ms"] are sums over the timed steps."""
+    if not fam:
+        return None
+    terms = {}
+    tot_ms = tot_floor = 0.0
+    for k, v in fam.items():
+        ms, fl = v["ms"] / steps, v["floor_ms"] / steps
+        terms[k] = {"ms_per_step": round(ms, 4), "floor_ms_per_step": round(fl, 4), "frac": round(fl / ms, 4) if ms > 0 else None,
+                    "roof": max(v["roofs"], key=v["roofs"].get) if v["roofs"] else None}
+        tot_ms += ms
+        tot_floor += fl
+    if prep_ms_per_step > 0 and not capture:
+        fl = prep_bytes_per_step / (HBM_PEAK_GBPS * 1e9) * 1e3
+        terms["column preparation"] = {"ms_per_step": round(prep_ms_per_step, 4), "floor_ms_per_step": round(fl, 4),
+                                       "frac": round(fl / prep_ms_per_step, 4), "roof": "hbm"}
+        tot_ms += prep_ms_per_step
+        tot_floor += fl
+    return {"frac": round(tot_floor / tot_ms, 4), "floor_ms_per_step": round(tot_floor, 3), "ms_per_step": round(tot_ms, 3),
+            "families": terms,
+            "definition": "sum over kernel families of (the floor the family's binding roof sets on its work) / sum of their measured "
+                          "times (events on the launch stream): <= 1 by construction.  Roofs: vector ALU = packed fp32 instructions "
+                          "of the sweeps x 4.45 SIMD cycles with two waves per SIMD, 5.2 per instruction of a single wave, at 2.4 GHz; "
+                          "vector L1 = column bytes a resident workgroup pulls / (64 B per clock per CU = 34.5 TB/s); exchange = "
+                          "0.65 us per column and round exposed in the lock-step kernels; HBM = 8 TB/s for the streaming kernels "
+                          "and the column preparation",
+            "sources": {"vector ALU": "profiles/r05_probe_valu.txt (tools/scratch/valu_probe.hip)",
+                        "exchange": "profiles/r03_xchg_probe.txt", "vector L1, HBM, clock": "MI355X_MICROARCH.md"}}
+
+
 def plan_rounds(desc):
     """Launches a layer's loop is spread over: a cooperative plan whose workgroups do not all fit on the chip runs one
     co-resident launch per block of rows (quantized_neural_nets_amd/csrc run_loop)."""
@@ -847,7 +922,10 @@ def main():
         mp = _lib.lib.gpfq_padded_m(m)
         l2b = l2_column_bytes(desc, max(Nl, 1), dg, mp, gl if Nl % gl == 0 else 1)
         ab = bw.algorithmic_bytes(Nl, dg, m, gl if Nl % gl == 0 else 1)
-        f = fam.setdefault(kind, {"ms": 0.0, "bytes": 0.0, "launches": 0, "l2": 0.0, "l2_known": True})
+        f = fam.setdefault(kind, {"ms": 0.0, "bytes": 0.0, "launches": 0, "l2": 0.0, "l2_known": True, "floor_ms": 0.0, "roofs": {}})
+        roof_name, floor_ms = roof_floor_ms(desc, dg, gl, ab, l2b)
+        f["floor_ms"] += floor_ms * rec["n"]
+        f["roofs"][roof_name] = f["roofs"].get(roof_name, 0.0) + floor_ms * rec["n"]
         f["ms"] += rec["loop_ms"]
         f["bytes"] += ab * rec["n"]
         f["launches"] += rec["n"] * plan_rounds(desc)
@@ -967,6 +1045,7 @@ def main():
             "roofline": roofline,
             "roofline_l2": roofline_l2,
             "roofline_issue": roofline_issue,
+            "roofline_bound": roofline_bound(fam, prep_ms_total, prep_bytes_total, args.steps, bool(args.capture)),
             "family_counters": (lambda r: r[0] if r[0] else {"source": None, "reason": r[1]})(
                 family_counter_fracs(list(fam), _lib.kernel_source_digest(), args.workload)) if fam else None,
             # the one HBM-bound part of a step: the column preparation (every rank repeats it in full)

@@ -265,7 +265,9 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
     if (pipel_mode != 0 && allow_pipe && !force_rt) {
         Plan pp = *pl;
         double pcost = 0.0;
-        if (choose_pipel(Ng, S, cus, &pp, &pcost, allow_rounds) && (!found || pipel_mode == 1 || pcost < best)) {
+        // (by more than 3 %: at a modelled tie the measured one goes to the four-group kernels -- 256 rows of 197 segments
+        // 9.99 against 10.36 us per column)
+        if (choose_pipel(Ng, S, cus, &pp, &pcost, allow_rounds) && (!found || pipel_mode == 1 || pcost < 0.97 * best)) {
             *pl = pp;
             best = pcost;
             found = true;
@@ -290,7 +292,8 @@ double pipe_step_cost(int RG, int waves, int C, bool local)
 {
     const int per_simd = (waves + 3) / 4;                                  // sweep waves on the fullest SIMD
     const double sweep = (RG == 1 ? 0.13 : 0.20) * per_simd + 0.13;
-    double gather = 0.38 + (waves >= 3 ? 0.04 : 0.0) + (RG * C >= 64 ? 0.02 : 0.0) + (RG * C > 64 ? 0.06 : 0.0);
+    // (64 granules per gather, seven sweep waves: measured in rounds 2.35-2.53 us per column on 197-segment rows, round 5)
+    double gather = 0.38 + (waves >= 3 ? 0.04 : 0.0) + (RG * C >= 64 ? (waves == 7 ? 0.08 : 0.02) : 0.0) + (RG * C > 64 ? 0.06 : 0.0);
     // (single rows with at most one sweep wave per SIMD: the sweep waves are at the barrier early and the gatherer's phase is the
     // shortest measured -- N = 128, 26 segments, four rows x 8 members: 1.36 us per column against 1.43 as eight rows x 16 members
     // and 1.46 on the lock-step two-row kernel)
@@ -354,7 +357,7 @@ double pipel_step_cost(int waves, int C)
 {
     const int per_simd = (waves + 3) / 4;
     const double sweep = 0.45 * per_simd + (waves > 4 ? 0.19 : 0.29);
-    const double gather = C > 32 ? 1.22 : 0.60;                       // (128 members: the reducer's re-polls; device scope throughout)
+    const double gather = C > 64 ? 1.22 : (C > 32 ? 1.0 : 0.60);      // (128 members: the reducer's re-polls; device scope throughout)
     return 3.0 * (sweep > gather ? sweep : gather);
 }
 

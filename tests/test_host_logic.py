@@ -118,7 +118,8 @@ def test_plan_selection(lib):
     # (four rows x 13 sweep waves: the variant that stages its columns through LDS)
     # (eight rows per tile, seven sweep waves + ONE reducer wave for both roles: the pipelined `_w8s` variant)
     assert lib.describe_plan(2048, 1024, 51200).startswith("coop RT=8 C=8 waves=7 S=50 grid=256 rounds=8 pipe=1")
-    assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=8 C=32 waves=7 S=197 grid=256 rounds=16 pipe=1")
+    assert lib.describe_plan(512, 128, 201728).startswith("coop RT=8 C=32 waves=7 S=197 grid=256 rounds=8 pipe=1")
+    assert lib.describe_plan(1024, 512, 201728).startswith("coop RT=12 C=32 waves=7 S=197 grid=256 rounds=11 pipel=1")   # 11 rounds of twelve rows against 16 of eight: 35.1 against 37.5-40.5 us per column
     # (round 5: twelve rows per tile in three groups, columns through LDS, 128 members: 11 rounds instead of the 16 of the four-row
     # lock-step kernel on 64 members, which stays selectable -- GPFQ_COOP_PIPEL=0)
     assert lib.describe_plan(256, 64, 803840).startswith("coop RT=12 C=128 waves=7 S=785 grid=256 rounds=11 pipel=1")
@@ -437,6 +438,39 @@ def test_bench_counter_rooflines_are_bounded_and_digest_gated(tmp_path, monkeypa
     assert l2["measured"] and l2["request_bytes"] == 128 and l2["model"] == {"frac": 0.45}
     assert abs(l2["achieved"] - 226.5e6 * 128 / 2.244e-3 / 1e9) < 0.1 and abs(l2["frac"] - l2["achieved"] / 34500.0) < 1e-4
     assert abs(l2["l2_hit_rate"] - 219.7 / 227.0) < 1e-4 and l2["frac"] <= 1.0
+
+
+def test_bench_roofline_bound_holds_every_family_against_the_roof_that_binds_it():
+    """roofline_bound (round 5): per kernel family a FLOOR on its time -- vector ALU (packed instructions x 4.45 SIMD cycles with two
+    waves per SIMD, 5.2 per instruction of a single wave, profiles/r05_probe_valu.txt), vector L1 (64 B per clock per CU), the
+    exposed exchange of the lock-step kernels (0.65 us, profiles/r03_xchg_probe.txt), HBM -- summed and divided by the measured
+    times: one fraction <= 1 for the whole step."""
+    import bench
+    us = lambda insts, per_simd: insts * max(5.2, 4.45 * per_simd) / 2.4e9 * 1e6           # noqa: E731
+    # twelve rows in three groups, seven sweep waves (two per SIMD): 3 x 160 packed instructions per column and round
+    name, ms = bench.roof_floor_ms("coop RT=12 C=128 waves=7 S=785 grid=256 rounds=11 pipel=1 d=64", 64, 1, 1e12, 1e9)
+    assert name == "vector ALU" and abs(ms - 64 * 11 * 3 * us(160, 2) * 1e-3) < 1e-9
+    # four groups of a row pair, six sweep waves: 4 x 80; of single rows with four sweep waves (one per SIMD: a wave's own issue rate)
+    assert abs(bench.roof_floor_ms("coop RT=8 C=16 waves=6 S=91 grid=256 pipe=1 d=1152", 1152, 1, 1e12, 1e9)[1] - 1152 * 4 * us(80, 2) * 1e-3) < 1e-9
+    assert abs(bench.roof_floor_ms("coop RT=4 C=8 waves=4 S=26 grid=256 pipe=1 d=1152", 1152, 1, 1e12, 1e9)[1] - 1152 * 4 * us(48, 1) * 1e-3) < 1e-9
+    # lock-step: the sweep of all rows, then an exposed exchange, per column and round
+    name, ms = bench.roof_floor_ms("coop RT=4 C=64 waves=13 S=785 grid=256 rounds=16 d=64", 64, 1, 1e12, 1e9)
+    assert name == "vector ALU + exchange" and abs(ms - 64 * 16 * (us(160, 4) + 0.65) * 1e-3) < 1e-9
+    # resident: the larger of the vector-L1 floor and the sweeps' issue floor
+    l2b = 256 * 2304 * 8 * 7168
+    name, ms = bench.roof_floor_ms("resident RT=1 waves=7 S=7 grid=(256,1) d=2304", 2304, 1, 1e12, l2b)
+    assert name == "vector L1" and abs(ms - l2b / 34.5e12 * 1e3) < 1e-9
+    name, ms = bench.roof_floor_ms("resident RT=2 waves=3 S=3 grid=(64,1) d=4608", 4608, 1, 1e12, 64 * 4608 * 8 * 3072)
+    assert name == "vector ALU" and abs(ms - 4608 * us(80, 1) * 1e-3) < 1e-9       # (a quarter of the CUs busy: the chain, not the L1)
+    assert bench.roof_floor_ms("stream RT=4 waves=8 S=50 grid=(64,1) d=10", 10, 1, 8e9, None) == ("hbm", 1.0)
+    # ... and the whole-step fraction: time-weighted, <= 1 whenever every family's floor is below its time
+    fam = {"a": {"ms": 20.0, "floor_ms": 10.0, "roofs": {"vector ALU": 10.0}}, "b": {"ms": 10.0, "floor_ms": 8.0, "roofs": {"vector L1": 8.0}}}
+    rb = bench.roofline_bound(fam, 2.0, 8e9, 10, False)
+    assert rb["families"]["column preparation"]["frac"] == 0.5 and rb["families"]["a"]["roof"] == "vector ALU"
+    assert abs(rb["frac"] - (1.0 + 0.8 + 1.0) / (2.0 + 1.0 + 2.0)) < 1e-4 and rb["frac"] <= 1.0
+    for src in rb["sources"].values():
+        if src.startswith("profiles/"):
+            assert os.path.exists(os.path.join(ROOT, src.split(" ")[0])), src
 
 
 def test_bench_self_launch_builds_the_drivers_command_and_never_touches_the_gpu(monkeypatch, capsys):
