@@ -64,11 +64,13 @@ def test_efficientnet_b1_all_layers_sparse_gpfq():
 
 def test_resnet50_all_distinct_layer_shapes():
     """config 3 (one GPU's worth): every distinct layer shape of ResNet-50's 54 layers at batch 1024 -- the 1x1 convs
-    that run in rounds on the LDS-staged four-row kernels included -- with full N, m, groups and 96 input features."""
+    that run in rounds on the twelve-row LDS-staged pipelined kernels (round 5; before: the four-row lock-step ones, which
+    tests/test_gpu_rounds.py keeps covered) included -- with full N, m, groups and 96 input features."""
     rec, err = run_bench("--workload", "r50_all", "--distinct-shapes", "--max-cols", "96")
     assert rec["config"]["layers"] == 24
     assert rec["oracle_shape_check"]["shapes"] == rec["config"]["layers"]
-    assert "gpfq_coop_rt4_m0_w16l" in rec["roofline"]["families"] or "gpfq_coop_rt4_m0_w16lq" in rec["roofline"]["families"]
+    assert "gpfq_pipel_m0_w8" in rec["roofline"]["families"] and "gpfq_pipe_rg2_m0_w8s" in rec["roofline"]["families"]
+    assert 0 < rec["roofline_bound"]["frac"] <= 1.0 and rec["roofline_bound"]["families"]["gpfq_pipel_m0_w8"]["roof"] == "vector ALU"
 
 
 def test_sharded_path_through_rccl_equals_unsharded(tmp_path):
