@@ -811,16 +811,6 @@ int launch_pipe(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scra
     return GPFQ_OK;
 }
 
-SlabKernel pipel2_kernel(int mode)
-{
-    switch (mode) {
-    case gpfq::MODE_SOFT: return gpfq::gpfq_pipel2_m1_w8;
-    case gpfq::MODE_HARD: return gpfq::gpfq_pipel2_m2_w8;
-    case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_pipel2_m3_w8;
-    default: return gpfq::gpfq_pipel2_m0_w8;
-    }
-}
-
 SlabKernel pipel_kernel(int mode)
 {
     switch (mode) {
@@ -837,9 +827,7 @@ int launch_pipel(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scr
     if (!p_d_fits_epoch(sp.d)) return fail(GPFQ_ERR_UNSUPPORTED, "pipelined cooperative kernels take fewer than 2^20 columns");
     if (pl.RT != gpfq::kPipelRows || pl.waves < 1 || pl.waves > 7 || pl.C > 128 || pl.C < 1)
         return fail(GPFQ_ERR_UNSUPPORTED, "internal: no LDS-staged pipelined kernel for this (rows, waves, members) triple");
-    // (GPFQ_PIPEL_GROUPS=2: two groups of six rows, two phases per step -- gpfq_pipel2_*)
-    const bool two = env_int("GPFQ_PIPEL_GROUPS", 3) == 2;
-    SlabKernel kern = two ? pipel2_kernel(mode) : pipel_kernel(mode);
+    SlabKernel kern = pipel_kernel(mode);
     const int threads = 64 * (pl.waves + 1);                           // + the reducer wave
     const size_t shm = gpfq::pipel_lds_bytes(pl.waves);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

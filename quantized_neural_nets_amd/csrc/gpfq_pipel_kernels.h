@@ -441,393 +441,6 @@ __device__ __forceinline__ void coop_pipel_body(const SlabParams& p)
 #undef GPFQ_FIN
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// TWO groups of SIX rows (gpfq_pipel2_*): the same twelve rows, the same LDS-staged columns, two phases per step.
-// What a phase costs besides its packed arithmetic -- q and the columns' first quarter out of LDS, the lane trees, the LDS
-// words, the weights, the barrier: ~90 of a sweep wave's 250 instructions -- is paid per PHASE, and the family is bound by the
-// SIMD's issue rate (two sweep waves per SIMD, 4.45 cycles per packed instruction: profiles/r05_probe_valu.txt): three pairs per
-// phase instead of two are 630 instead of 750 instructions per wave and step.  The price: a group's exchange has ONE phase --
-// published at the top of the phase after its sweep, requested behind a pause, gathered, quantized and in LDS before that
-// phase's barrier, because the group is swept again in the next one.  A phase of three pairs on two waves per SIMD is ~2 800
-// cycles, the chain publish -> visible -> requested -> landed -> quantized ~2 000: it fits, without slack for a second look.
-// Granules: xbuf[tile][parity][group][pair plane (3)][position][2 rows]: a plane is one contiguous run of 16-byte items, lane
-// (plane, j) of the gather loads planes 0 and 1 in the two halves of the wave and plane 2 in a second set of loads (lanes 0..31).
-// ------------------------------------------------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void pipel2_reducer(const SlabParams& p, const float* segs, float* qs, int NS, int lane, int tile, int c,
-                                               int C, int nl, int seg_lo, int row0)
-{
-    constexpr int G = 2, RG = 6, RT = 12, GV = 64;
-    constexpr bool FAST = MODE == MODE_MSQ;
-    const int nph = G * p.d;
-    unsigned long long* const xb = p.xbuf + (unsigned)tile * (unsigned)(2 * G * RG) * (unsigned)C;
-    const unsigned block = (unsigned)(C * RG);                 // granules of one (parity, group)
-    const unsigned plane = 2u * (unsigned)C;                   // granules of one pair plane
-    // ---- publisher: pass A rows 0..3 (lane = 16 * row + slot), pass B rows 4, 5 (lanes 0..31)
-    const int P = pow2_ceil(p.S);
-    const SlotMap smap = make_slot_map(p.S, P, c * nl, 1, lane & 15, nl);
-    const int r16 = lane >> 4;
-    const bool mine = (smap.mask & 1u) != 0;
-    const int seg_a = r16 * NS + (smap.s0 - seg_lo);
-    const int seg_b = (4 + (r16 & 1)) * NS + (smap.s0 - seg_lo);
-    const int GPL = C > 32 ? C >> 5 : 1;                       // members per lane of a gather: 1, 2 or 4 (C <= 128)
-    const unsigned pos = (unsigned)(c % GPL) * 32u + (unsigned)(c / GPL);
-    const unsigned pub_a = (unsigned)(r16 >> 1) * plane + 2u * pos + (unsigned)(r16 & 1);
-    const unsigned pub_b = 2u * plane + 2u * pos + (unsigned)(r16 & 1);
-    const unsigned my_xcc = pipe_xcc_id();
-    const unsigned tag = pipe_epoch_tag(p.salt);
-    // ---- gatherer: set 1 = planes 0 / 1 in lanes 0..31 / 32..63, set 2 = plane 2 in lanes 0..31
-    const kfloat* nrm = as_scalar(p.nrm2);
-    float* hist = qs + RT;
-    const int half = lane >> 5, j = lane & 31;
-    const int lpr = C / GPL;
-    const bool want = j < lpr;
-    const bool want2 = want && half == 0;
-    const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
-    const unsigned long long idle2 = ~__builtin_amdgcn_ballot_w64(want2);
-    // one quantizer pass for six rows: rows 0..3 in lanes 0, 16, 32, 48; rows 4, 5 in lanes 8, 24
-    const bool lead = (lane & 7) == 0 && (!(lane & 8) || lane < 32);
-    const int lead_row = (lane & 8) ? 4 + ((lane >> 4) & 1) : lane >> 4;
-    const unsigned long long unused = ~__builtin_amdgcn_ballot_w64(lead);
-    const unsigned bytes1 = want ? 8u * plane * (unsigned)half + 16u * (unsigned)j : 0u;
-    const unsigned bytes2 = want ? 16u * plane + 16u * (unsigned)j : 0u;       // (lanes 32..63 repeat lanes 0..31: in bounds, ignored)
-    auto request = [&](const unsigned long long* base) {
-#define GPFQ_RQ(i, off, reg, addr)                                                                                           \
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c2+3], %0, %1 offset:%c3 sc1" :: "v"(addr), "s"(base), "n"(reg), "n"(off) : "memory");
-        GPFQ_RQ(0, 0, GV, bytes1) GPFQ_RQ(0, 0, GV + 16, bytes2)
-        if (GPL >= 2) { GPFQ_RQ(1, 512, GV + 4, bytes1) GPFQ_RQ(1, 512, GV + 20, bytes2) }
-        if (GPL >= 4) {
-            GPFQ_RQ(2, 1024, GV + 8, bytes1) GPFQ_RQ(2, 1024, GV + 24, bytes2)
-            GPFQ_RQ(3, 1536, GV + 12, bytes1) GPFQ_RQ(3, 1536, GV + 28, bytes2)
-        }
-#undef GPFQ_RQ
-    };
-    unsigned glo0[8], ghi0[8], glo1[8], ghi1[8];               // [set 1 loads 0..3, set 2 loads 4..7]
-    auto read_out = [&]() {
-#define GPFQ_RDL(i)                                                                                                          \
-        asm volatile("v_mov_b32 %0, v[%c4]\n\tv_mov_b32 %1, v[%c4+1]\n\tv_mov_b32 %2, v[%c4+2]\n\tv_mov_b32 %3, v[%c4+3]\n\ts_nop 0" \
-                     : "=v"(glo0[i]), "=v"(ghi0[i]), "=v"(glo1[i]), "=v"(ghi1[i]) : "n"(GV + 4 * i) : "memory");
-        GPFQ_RDL(0) GPFQ_RDL(4)
-        if (GPL >= 2) { GPFQ_RDL(1) GPFQ_RDL(5) }
-        if (GPL >= 4) { GPFQ_RDL(2) GPFQ_RDL(3) GPFQ_RDL(6) GPFQ_RDL(7) }
-#undef GPFQ_RDL
-    };
-    auto arrived_pair = [&](int i, unsigned epoch) {
-        return __builtin_amdgcn_ballot_w64((ghi0[i] & 0x0fffffffu) == epoch) & __builtin_amdgcn_ballot_w64((ghi1[i] & 0x0fffffffu) == epoch);
-    };
-    auto all_arrived = [&](unsigned epoch) {
-        unsigned long long ok1 = arrived_pair(0, epoch), ok2 = arrived_pair(4, epoch);
-        if (GPL >= 2) { ok1 &= arrived_pair(1, epoch); ok2 &= arrived_pair(5, epoch); }
-        if (GPL >= 4) { ok1 &= arrived_pair(2, epoch) & arrived_pair(3, epoch); ok2 &= arrived_pair(6, epoch) & arrived_pair(7, epoch); }
-        const unsigned long long ex = __builtin_amdgcn_read_exec();
-        return (ok1 | idle) == ex && (ok2 | idle2) == ex;
-    };
-    bool gave_up = false;
-    if (p.xcd_tiles == 3) __builtin_amdgcn_s_setprio(3);
-    else if (p.xcd_tiles == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p.xcd_tiles == 1) __builtin_amdgcn_s_setprio(1);
-    int ga = 0, ta = 0;                                        // the group swept in the phase before: published AND consumed in this one
-    GPFQ_PSTAMP_DECL
-    for (int ph = 0; ph <= nph; ++ph) {
-        GPFQ_PSTAMP(0)                                       // the barrier
-        if (ph >= 1) {
-            // ---- (a) this member's block of the slot tree for the six rows of the group, published
-            const float va = wave_tree16_zero_padded(mine ? segs[ga * RG * NS + seg_a] : 0.0f);
-            const float vb = wave_tree16_zero_padded((mine && r16 < 2) ? segs[ga * RG * NS + seg_b] : 0.0f);
-            unsigned long long* dst = xb + (unsigned)((ta & 1) * G + ga) * block;
-            const unsigned long long ep = (unsigned long long)(tag | (my_xcc << 28) | ((unsigned)ta + 1u)) << 32;
-            if ((lane & 15) == 0) {
-                __hip_atomic_store(dst + pub_a, ep | (unsigned long long)__float_as_uint(va), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (r16 < 2) __hip_atomic_store(dst + pub_b, ep | (unsigned long long)__float_as_uint(vb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            GPFQ_PSTAMP(1)                                   // slot tree + publish
-            // ---- (c) the pause (the other members publish in this same phase of theirs), then the request
-            {
-                unsigned w = p.spin_limit & 31u;
-                asm volatile("s_cmp_eq_u32 %0, 0\n\t"
-                             "s_cbranch_scc1 2f\n"
-                             "1:\n\t"
-                             "s_sleep 1\n\t"
-                             "s_sub_u32 %0, %0, 1\n\t"
-                             "s_cmp_lg_u32 %0, 0\n\t"
-                             "s_cbranch_scc1 1b\n"
-                             "2:" : "+s"(w) :: "scc", "memory");
-            }
-            const unsigned long long* src = dst;
-            request(src);
-            // ---- (b) ... and the same group consumed: gather, tree over the members, quantizer, q into LDS before the barrier
-            const unsigned epoch = tag | ((unsigned)ta + 1u);
-            const float n2cur = sload(nrm, 8u * (unsigned)ta);
-            const float in2cur = sload(nrm, 8u * (unsigned)ta + 4u);
-            bool timed_out = false;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_out();
-            GPFQ_PSTAMP(2)                                   // pause, request, landing
-            if (__builtin_expect(!all_arrived(epoch), 0)) {
-                unsigned spins = gave_up ? p.spin_limit : 0u;
-                do {
-                    if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    request(src);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    read_out();
-                } while (!all_arrived(epoch));
-            }
-            if (ph == 1 && (p.spin_limit >> 8) == 0u) timed_out = true;      // (a limit of zero polls: a deterministic timeout for the tests)
-            GPFQ_PSTAMP(3)                                   // re-polls
-            auto lane_sum = [&](const unsigned (&g)[8], int b) {            // (g0 + g1) + (g2 + g3) of the lane's members; loads beyond GPL hold nothing
-                const float v0 = __uint_as_float(g[b]);
-                const float v1 = GPL >= 2 ? __uint_as_float(g[b + 1]) : 0.0f;
-                const float v2 = GPL >= 4 ? __uint_as_float(g[b + 2]) : 0.0f;
-                const float v3 = GPL >= 4 ? __uint_as_float(g[b + 3]) : 0.0f;
-                return (v0 + v1) + (v2 + v3);
-            };
-            float x = want ? lane_sum(glo0, 0) : 0.0f, y = want ? lane_sum(glo1, 0) : 0.0f;
-            float x2 = want2 ? lane_sum(glo0, 4) : 0.0f, y2 = want2 ? lane_sum(glo1, 4) : 0.0f;
-            x = xor16_add(wave_tree16_zero_padded(x));
-            y = xor16_add(wave_tree16_zero_padded(y));
-            x2 = xor16_add(wave_tree16_zero_padded(x2));
-            y2 = xor16_add(wave_tree16_zero_padded(y2));
-            const float v14 = (lane & 16) ? y : x;               // rows 0..3 in lane rows 0..3
-            const float v56 = (lane & 16) ? y2 : x2;             // rows 4, 5 in lane rows 0, 1
-            const float v = (lane & 8) ? v56 : v14;
-            const int rr = ga * RG + lead_row;                   // row of the tile
-            const bool rvalid = lead && (row0 + rr < p.Ng);
-            const int64_t growl = (int64_t)row0 + (rvalid ? rr : 0);
-            int id;
-            float q;
-            bool redo = false;
-            auto divide_and_quantize = [&]() {
-                const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
-                q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)ta, id);
-            };
-            if (FAST) redo = !quant_msq_from_dot(v, in2cur, p.inv_step, p.step, p.Kf, p.msq_thr, unused, q, id);
-            else divide_and_quantize();
-            auto commit = [&]() {
-                if (lead) {
-                    qs[rr] = q;
-                    hist[rr * 64 + (ta & 63)] = q;
-                    hist[(RT + rr) * 64 + (ta & 63)] = __int_as_float(id);
-                }
-            };
-            commit();
-            if (FAST && __builtin_expect(redo, 0)) {
-                divide_and_quantize();
-                commit();
-            }
-            if (__builtin_expect((ta & 63) == 63 || ta + 1 == p.d, 0)) {
-                const int t0 = ta & ~63;
-                const int n = ta - t0 + 1;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int ln = fresh_lane_id();
-                if (c == 0 && ln < n) {
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        const int row = ga * RG + r;
-                        if (row0 + row < p.Ng) {
-                            const int64_t gw = (int64_t)row0 + row;
-                            p.Q[gw * p.ldq + t0 + ln] = hist[row * 64 + ln];
-                            if (p.idx) {
-                                const int iv = __float_as_int(hist[(RT + row) * 64 + ln]);
-                                if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + ln] = (int8_t)iv;
-                                else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + ln] = (int16_t)iv;
-                            }
-                        }
-                    }
-                }
-            }
-            if (__builtin_expect(timed_out && !gave_up, 0) && lane == 0) {
-                atomicExch(p.status, 1);
-                p.status[1] = ta; p.status[2] = tile; p.status[3] = c;
-            }
-            gave_up |= timed_out;
-            if (++ga == G) { ga = 0; ++ta; }
-            GPFQ_PSTAMP(4)                                   // tree over the members, quantizer, q into LDS, rare flush
-        }
-        pipe_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GPFQ_PSTAMP_DUMP(0)
-}
-
-template <int MODE>
-__device__ __forceinline__ void coop_pipel2_body(const SlabParams& p)
-{
-    constexpr int G = 2, RG = 6, RT = 12, U0 = 64;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // cols [NS][5][1024], segs [RT][NS], qs [RT], history [2 RT][64]
-    const int NW = blockDim.x >> 6;
-    const int NS = NW - 1;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int S = p.S, C = p.C;
-    const int P = pow2_ceil(S);
-    if (*static_cast<volatile const int*>(p.status) != 0) return;
-    const int tile = blockIdx.x / C, c = blockIdx.x % C;
-    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
-    const int n_own = seg_hi - seg_lo;
-    const bool active = wave < n_own;
-    const int myseg = seg_lo + (active ? wave : 0);
-    const int nl = P / C;
-
-    float* cols = smem + (size_t)(wave < NS ? wave : 0) * kPipelColFloats;
-    float* segs = smem + (size_t)NS * kPipelColFloats;
-    float* qs = segs + RT * NS;
-    const int row0 = tile * RT;
-    if (threadIdx.x < RT) qs[threadIdx.x] = 0.0f;
-    pipe_barrier();
-    if (wave == NS) {
-        pipel2_reducer<MODE>(p, segs, qs, NS, lane, tile, c, C, nl, seg_lo, row0);
-        return;
-    }
-
-    const kfloat* wrow[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int64_t gr = (int64_t)row0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
-        wrow[r] = as_scalar(p.W + gr * p.ldw);
-    }
-    win_zero16<U0>(); win_zero16<U0 + 16>(); win_zero16<U0 + 32>(); win_zero16<U0 + 48>();
-    win_zero16<U0 + 64>(); win_zero16<U0 + 80>(); win_zero16<U0 + 96>(); win_zero16<U0 + 112>();
-    win_zero16<U0 + 128>(); win_zero16<U0 + 144>(); win_zero16<U0 + 160>(); win_zero16<U0 + 176>();
-
-    const unsigned lane_off = 16u * (unsigned)lane;
-    const unsigned cols_lds = (unsigned)(uintptr_t)cols;
-    const float* xg = p.XT + (int64_t)myseg * kSeg;
-    const float* ag = p.AT + (int64_t)myseg * kSeg;
-    if (active) {
-        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<float4*>(cols + 2048 + 256 * q4 + 4 * lane) = z;
-        pipel_dma(xg, lane_off, cols_lds);
-        pipel_dma(ag, lane_off, cols_lds + 3u * 4096u);
-    }
-    float wn[RG];
-#pragma unroll
-    for (int r = 0; r < RG; ++r) wn[r] = wrow[r][0];
-    int t = 0;
-    int xi = 0;
-    const int dlast = p.d - 1;
-    GPFQ_PSTAMP_DECL
-
-    auto phase = [&](auto g_) {
-        constexpr int g = decltype(g_)::value;
-        constexpr int UG = U0 + 16 * RG * g;
-        GPFQ_PSTAMP(0)
-        const float2 qa = *reinterpret_cast<const float2*>(qs + RG * g), qb = *reinterpret_cast<const float2*>(qs + RG * g + 2),
-                     qc = *reinterpret_cast<const float2*>(qs + RG * g + 4);
-        const v2f ww01 = {wn[0], wn[1]}, ww23 = {wn[2], wn[3]}, ww45 = {wn[4], wn[5]};
-        const int xn = xi == 2 ? 0 : xi + 1, xpi = xi == 0 ? 2 : xi - 1;
-        if constexpr (g == 0) {
-            const int64_t adv = (t + 1 < p.d) ? p.m_pad : 0;
-            xg += adv;
-            ag += adv;
-            if (active) {
-                pipel_wait_columns();
-                pipel_dma(xg, lane_off, cols_lds + (unsigned)xn * 4096u);
-                pipel_dma(ag, lane_off, cols_lds + (3u + (unsigned)((t + 1) & 1)) * 4096u);
-            }
-        }
-        GPFQ_PSTAMP(1)
-        if (active) {
-            const float* xc = cols + xi * 1024;
-            const float* xp = cols + xpi * 1024;
-            const float* ab = cols + (3 + (t & 1)) * 1024;
-            v2f acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}, acc45 = {0.0f, 0.0f};
-            const v2f qq01 = {qa.x, qa.y}, qq23 = {qb.x, qb.y}, qq45 = {qc.x, qc.y};
-            float4 x4 = *reinterpret_cast<const float4*>(xc + 4 * lane);
-            float4 a4 = *reinterpret_cast<const float4*>(ab + 4 * lane);
-            float4 p4 = *reinterpret_cast<const float4*>(xp + 4 * lane);
-            auto quarter = [&](auto c_) {
-                constexpr int cq = decltype(c_)::value;
-                float4 nx = x4, na = a4, np = p4;
-                if constexpr (cq < 3) {
-                    nx = *reinterpret_cast<const float4*>(xc + 256 * (cq + 1) + 4 * lane);
-                    na = *reinterpret_cast<const float4*>(ab + 256 * (cq + 1) + 4 * lane);
-                    np = *reinterpret_cast<const float4*>(xp + 256 * (cq + 1) + 4 * lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const v2f x01 = {x4.x, x4.y}, x23 = {x4.z, x4.w}, a01 = {a4.x, a4.y}, a23 = {a4.z, a4.w};
-                const v2f p01 = {p4.x, p4.y}, p23 = {p4.z, p4.w};
-                win_sweep4_pair_lds<UG + 8 * cq>(acc01, qq01, ww01, p01, p23, a01, a23, x01, x23);
-                win_sweep4_pair_lds<UG + 32 + 8 * cq>(acc23, qq23, ww23, p01, p23, a01, a23, x01, x23);
-                win_sweep4_pair_lds<UG + 64 + 8 * cq>(acc45, qq45, ww45, p01, p23, a01, a23, x01, x23);
-                __builtin_amdgcn_sched_barrier(0);
-                x4 = nx; a4 = na; p4 = np;
-            };
-            quarter(std::integral_constant<int, 0>{});
-            quarter(std::integral_constant<int, 1>{});
-            quarter(std::integral_constant<int, 2>{});
-            quarter(std::integral_constant<int, 3>{});
-            GPFQ_PSTAMP(2)
-            const float acc4[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
-            const float acc2[2] = {acc45.x, acc45.y};
-            const float tot4 = wave_tree64_rows<4>(acc4);    // row r's total in lane row r
-            const float tot2 = wave_tree64_rows<2>(acc2);    // rows 4, 5 in lane rows 0, 1 (and again in 2, 3)
-            if ((lane & 15) == 0) {
-                segs[(g * RG + (lane >> 4)) * NS + wave] = tot4;
-                if (lane < 32) segs[(g * RG + 4 + (lane >> 4)) * NS + wave] = tot2;
-            }
-            GPFQ_PSTAMP(3)
-        }
-        {
-            constexpr int gn = (g + 1) % G;
-            unsigned tn4 = 4u * (unsigned)(g == G - 1 ? (t < dlast ? t + 1 : dlast) : t);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+s"(tn4)::"memory");
-#pragma unroll
-            for (int r = 0; r < RG; ++r) wn[r] = sload(wrow[gn * RG + r], tn4);
-        }
-        GPFQ_PSTAMP(4)
-        pipe_barrier();
-    };
-    for (;;) {
-        phase(std::integral_constant<int, 0>{});
-        phase(std::integral_constant<int, 1>{});
-        if (++t >= p.d) break;
-        xi = xi == 2 ? 0 : xi + 1;
-    }
-    pipe_barrier();                                  // the reducer is one phase behind the last sweep
-    pipel_wait_columns();
-#ifdef GPFQ_STAMPS
-    if (wave == (p.pace >= 100 ? p.pace - 100 : 0)) { GPFQ_PSTAMP_DUMP(8) }
-#endif
-    if (!active) return;
-    {
-        const float* xl = cols + xi * 1024;
-        const float4 qa = *reinterpret_cast<const float4*>(qs), qb = *reinterpret_cast<const float4*>(qs + 4),
-                     qc = *reinterpret_cast<const float4*>(qs + 8);
-        const v2f q01 = {qa.x, qa.y}, q23 = {qa.z, qa.w}, q45 = {qb.x, qb.y}, q67 = {qb.z, qb.w}, q89 = {qc.x, qc.y}, qab = {qc.z, qc.w};
-        auto quarter = [&](auto c_) {
-            constexpr int cq = decltype(c_)::value;
-            const float4 x4 = *reinterpret_cast<const float4*>(xl + 256 * cq + 4 * lane);
-            const v2f x01 = {x4.x, x4.y}, x23 = {x4.z, x4.w};
-            win_final_sub4_pair_lds<U0 + 8 * cq>(q01, x01, x23);
-            win_final_sub4_pair_lds<U0 + 32 + 8 * cq>(q23, x01, x23);
-            win_final_sub4_pair_lds<U0 + 64 + 8 * cq>(q45, x01, x23);
-            win_final_sub4_pair_lds<U0 + 96 + 8 * cq>(q67, x01, x23);
-            win_final_sub4_pair_lds<U0 + 128 + 8 * cq>(q89, x01, x23);
-            win_final_sub4_pair_lds<U0 + 160 + 8 * cq>(qab, x01, x23);
-        };
-        quarter(std::integral_constant<int, 0>{});
-        quarter(std::integral_constant<int, 1>{});
-        quarter(std::integral_constant<int, 2>{});
-        quarter(std::integral_constant<int, 3>{});
-    }
-#define GPFQ_FIN(k)                                                                                                          \
-    finish_row_w<U0 + 32 * k, 0, 2, false>(p, 0.0f, row0 + 2 * k < p.Ng, (int64_t)row0 + 2 * k, myseg, lane);               \
-    finish_row_w<U0 + 32 * k + 1, 0, 2, false>(p, 0.0f, row0 + 2 * k + 1 < p.Ng, (int64_t)row0 + 2 * k + 1, myseg, lane);
-    GPFQ_FIN(0) GPFQ_FIN(1) GPFQ_FIN(2) GPFQ_FIN(3) GPFQ_FIN(4) GPFQ_FIN(5)
-#undef GPFQ_FIN
-}
-
-#define GPFQ_DEFINE_PIPEL2(MODE)                                                                                  \
-    __global__ void __launch_bounds__(64 * 8) __attribute__((amdgpu_num_vgpr(64 / 2)))                            \
-    gpfq_pipel2_m##MODE##_w8(const SlabParams p)                                                                  \
-    {                                                                                                             \
-        asm volatile("" ::: "v255");                                                                              \
-        coop_pipel2_body<MODE>(p);                                                                                \
-    }
-GPFQ_DEFINE_PIPEL2(0) GPFQ_DEFINE_PIPEL2(1) GPFQ_DEFINE_PIPEL2(2) GPFQ_DEFINE_PIPEL2(3)
-
 // <= 8 waves (7 sweep waves + the reducer): 256 registers = the window's 192 (twelve residual rows) + 64 for the compiler
 #define GPFQ_DEFINE_PIPEL(MODE)                                                                                   \
     __global__ void __launch_bounds__(64 * 8) __attribute__((amdgpu_num_vgpr(64 / 2)))                            \

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for P in 16 20 24 28; do
+DLIMIT=128 timeout -k 10 300 python3 tools/layer_bench.py "256,64,803840" "1024,512,201728" "512,128,201728" "1024,256,51200" "2048,1024,51200" "64,147,263168" "plan=0,GPFQ_COOP_PIPEL=1,GPFQ_PIPEL_GROUPS=2,GPFQ_PIPEL_REQUEST_PAUSE=$P" 2>&1 | grep us/col | awk '{print $1,$3,$4,$(NF-4),$(NF-3),$(NF-2),$(NF-1),$NF}'
+done
