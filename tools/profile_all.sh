@@ -14,6 +14,12 @@ bash tools/profile_bench.sh $TAG > gpurun_out/${TAG}_profile_bench.log 2>&1 || e
 bash tools/profile_counters.sh $TAG > gpurun_out/${TAG}_profile_counters.log 2>&1 || exit 1
 bash tools/profile_workload.sh r50_all $TAG > /dev/null 2>&1 || exit 1
 bash tools/profile_workload.sh effnet_b1 $TAG > /dev/null 2>&1 || exit 1
+# round 5: the counter passes of the secondary workload whose kernels the headline does not launch (every distinct layer shape of
+# ResNet-50, full N / m / groups, 96 input features per group), and quantize_network() itself on the four architectures
+bash tools/profile_counters.sh $TAG "--workload r50_all --distinct-shapes --max-cols 96" _r50_all > gpurun_out/${TAG}_profile_counters_r50_all.log 2>&1 || exit 1
+for D in r18 r50 vgg16 effnet_b1; do
+  python3 bench.py --driver $D > gpurun_out/${TAG}_driver_${D}.json 2> gpurun_out/${TAG}_driver_${D}.err || exit 1
+done
 # bench.py quotes a PMC summary only from profiles/: copy <tag>_pmc_*.json there and run tools/bench_lines.sh once more for
 # the headline line that carries roofline.traffic, roofline_issue and the measured roofline_l2
 ls -la gpurun_out/${TAG}_* | awk '{print $5, $9}'
