@@ -62,7 +62,6 @@ struct Plan {
     int grouped;   // coop: one row per group (depthwise convolutions), every row with its own columns
     int pipe;      // coop: 1 = the PIPELINED kernels (gpfq_pipe_kernels.h): RT = 4 or 8 rows in four groups, reducer wave(s) of their own;
                    //       2 = the pipelined kernels with LDS-staged columns (gpfq_pipel_kernels.h): RT = 12 rows in three groups
-                   //       3 = eight rows in TWO groups of four, one phase per exchange (gpfq_pipe2_*): tiles of <= 32 members
 };
 
 int device_cu_count()
@@ -198,7 +197,6 @@ double stream_col_cost(int64_t Ng, int S, int cus)
 // Depends on (Ng, S, CU count) only -- never on the data.  cost_out: microseconds per column for all rows.
 bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_out, bool allow_rounds);
 bool choose_pipel(int64_t Ng, int S, int cus, Plan* pl, double* cost_out, bool allow_rounds);
-bool choose_pipe2(int64_t Ng, int S, int cus, Plan* pl, double* cost_out, bool allow_rounds);
 
 // allow_pipe false: the lock-step kernels only -- for layers the pipelined kernels cannot take (2^20 columns or more: their
 // epoch word) and for the retry after a pipelined launch was refused (run_loop)
@@ -270,17 +268,6 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
         // (by more than 3 %: at a modelled tie the measured one goes to the four-group kernels -- 256 rows of 197 segments
         // 9.99 against 10.36 us per column)
         if (choose_pipel(Ng, S, cus, &pp, &pcost, allow_rounds) && (!found || pipel_mode == 1 || pcost < 0.97 * best)) {
-            *pl = pp;
-            best = pcost;
-            found = true;
-        }
-    }
-    // ... and eight rows in two groups of four (GPFQ_COOP_PIPE2: 0 never, 1 wherever a configuration exists)
-    const int pipe2_mode = env_int("GPFQ_COOP_PIPE2", pipe_mode == 0 ? 0 : -1);
-    if (pipe2_mode != 0 && allow_pipe && !force_rt) {
-        Plan pp = *pl;
-        double pcost = 0.0;
-        if (choose_pipe2(Ng, S, cus, &pp, &pcost, allow_rounds) && (!found || pipe2_mode == 1 || pcost < 0.97 * best)) {
             *pl = pp;
             best = pcost;
             found = true;
@@ -399,45 +386,6 @@ bool choose_pipel(int64_t Ng, int S, int cus, Plan* pl, double* cost_out, bool a
             best = cost;
             pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
             pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0; pl->pipe = 2;
-        }
-    }
-    if (found && cost_out) *cost_out = best;
-    return found;
-}
-
-// One column step of the two-group kernels (gpfq_pipe2_*), microseconds: two phases, each the sweep of two pairs on the fullest
-// SIMD plus the four-row lane tree, or what the group's one-phase exchange needs.  (Measured: profiles/NOTES.md, round 5.)
-double pipe2_step_cost(int waves, int C)
-{
-    const int per_simd = (waves + 3) / 4;
-    const double sweep = 0.36 * per_simd + 0.15;
-    const double exchange = C > 16 ? 0.85 : 0.75;
-    return 2.0 * (sweep > exchange ? sweep : exchange);
-}
-
-bool choose_pipe2(int64_t Ng, int S, int cus, Plan* pl, double* cost_out, bool allow_rounds)
-{
-    const int force_c = env_int("GPFQ_COOP_C", 0);
-    const int RT = 8;
-    const int64_t tiles = (Ng + RT - 1) / RT;
-    double best = 1e30;
-    bool found = false;
-    for (int C = 32; C >= 2; C >>= 1) {                                   // (64 / 128 members: the exchange does not fit one phase)
-        if (force_c && C != force_c) continue;
-        if (C > S || C > cus) continue;
-        const int NW = (S + C - 1) / C;
-        if (NW > 7 || pow2_ceil_host(S) / C > 16) continue;
-        const int64_t tiles_round = tiles * C <= cus ? tiles : cus / C;
-        if (tiles_round < 1) continue;
-        const int64_t rounds = (tiles + tiles_round - 1) / tiles_round;
-        if (rounds > 1 && !allow_rounds) continue;
-        if ((size_t)tiles_round * 2 * C * RT * sizeof(unsigned long long) > kScratchStatusOffset) continue;
-        const double cost = (double)rounds * pipe2_step_cost(NW, C);
-        if (!found || cost < best - 1e-9) {
-            found = true;
-            best = cost;
-            pl->kind = GPFQ_PLAN_COOP; pl->RT = RT; pl->C = C; pl->tiles = (int)tiles; pl->waves = NW; pl->S = S;
-            pl->rounds = (int)rounds; pl->tiles_round = (int)tiles_round; pl->grouped = 0; pl->pipe = 3;
         }
     }
     if (found && cost_out) *cost_out = best;
@@ -908,51 +856,8 @@ int launch_pipel(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scr
     return GPFQ_OK;
 }
 
-SlabKernel pipe2_kernel(int mode)
-{
-    switch (mode) {
-    case gpfq::MODE_SOFT: return gpfq::gpfq_pipe2_m1_w8;
-    case gpfq::MODE_HARD: return gpfq::gpfq_pipe2_m2_w8;
-    case gpfq::MODE_STOCHASTIC: return gpfq::gpfq_pipe2_m3_w8;
-    default: return gpfq::gpfq_pipe2_m0_w8;
-    }
-}
-
-// eight rows in two groups of four, columns in the register window (gpfq_pipel_kernels.h, gpfq_pipe2_*)
-int launch_pipe2(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
-{
-    if (!p_d_fits_epoch(sp.d)) return fail(GPFQ_ERR_UNSUPPORTED, "pipelined cooperative kernels take fewer than 2^20 columns");
-    if (pl.RT != 8 || pl.waves < 1 || pl.waves > 7 || pl.C > 128 || pl.C < 1)
-        return fail(GPFQ_ERR_UNSUPPORTED, "internal: no two-group pipelined kernel for this (rows, waves, members) triple");
-    SlabKernel kern = pipe2_kernel(mode);
-    const int threads = 64 * (pl.waves + 1);                           // + the reducer wave
-    const size_t shm = sizeof(float) * ((size_t)pl.RT * pl.waves + pl.RT + 2 * (size_t)pl.RT * 64 + 4);
-    const int cus = device_cu_count();
-    const int nblocks = pl.tiles * pl.C;
-    int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, shm);
-    if (e != hipSuccess) return hip_fail(e, "occupancy query");
-    if (nb < 1 || nblocks > cus) return fail(GPFQ_ERR_UNSUPPORTED, "cooperative grid does not fit on the device");
-    size_t xbytes = (size_t)pl.tiles * 2 * pl.C * pl.RT * sizeof(unsigned long long);
-    xbytes = (xbytes + 15) & ~(size_t)15;
-    if (xbytes > kScratchStatusOffset) return fail(GPFQ_ERR_UNSUPPORTED, "exchange buffer larger than the scratch area");
-    e = hipMemsetAsync(scratch, 0, xbytes, st);
-    if (e != hipSuccess) return hip_fail(e, "exchange buffer memset");
-    gpfq::SlabParams spx = sp;
-    // low five bits: the reducer's pause between its publish and its gather request, in units of 64 clocks
-    spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_PIPE2_REQUEST_PAUSE", 8) & 31u);
-    spx.xcd_tiles = env_int("GPFQ_PIPEL_REDUCER_PRIO", 2) & 3;
-    static std::atomic<unsigned> launch_number{0};
-    spx.salt = launch_number.fetch_add(1) & 255u;
-    spx.allow_local = 0;
-    e = launch_waiting_grid(kern, dim3((unsigned)nblocks, 1, 1), dim3((unsigned)threads), shm, st, spx);
-    if (e != hipSuccess) return hip_fail(e, "GPFQ two-group pipelined cooperative kernel launch");
-    return GPFQ_OK;
-}
-
 int launch_coop(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scratch, hipStream_t st)
 {
-    if (pl.pipe == 3) return launch_pipe2(pl, sp, mode, scratch, st);
     if (pl.pipe == 2) return launch_pipel(pl, sp, mode, scratch, st);
     if (pl.pipe) return launch_pipe(pl, sp, mode, scratch, st);
     const int RT = pl.RT;
@@ -1542,10 +1447,10 @@ int gpfq_describe_plan_mode(int64_t N, int64_t d_g, int64_t m, int groups, int p
                      pl.tiles_round * pl.C, pl.rounds, groups, (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_COOP && pl.rounds > 1)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d rounds=%d%s d=%lld", pl.RT, pl.C, pl.waves, pl.S,
-                     pl.tiles_round * pl.C, pl.rounds, pl.pipe == 3 ? " pipe2=1" : pl.pipe == 2 ? " pipel=1" : pl.pipe ? " pipe=1" : "", (long long)d_g);
+                     pl.tiles_round * pl.C, pl.rounds, pl.pipe == 2 ? " pipel=1" : pl.pipe ? " pipe=1" : "", (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_COOP)
             snprintf(buf, buf_bytes, "coop RT=%d C=%d waves=%d S=%d grid=%d%s d=%lld", pl.RT, pl.C, pl.waves, pl.S,
-                     pl.tiles * pl.C, pl.pipe == 3 ? " pipe2=1" : pl.pipe == 2 ? " pipel=1" : pl.pipe ? " pipe=1" : "", (long long)d_g);
+                     pl.tiles * pl.C, pl.pipe == 2 ? " pipel=1" : pl.pipe ? " pipe=1" : "", (long long)d_g);
         else if (pl.kind == GPFQ_PLAN_STREAM && pl.C > 1)
             snprintf(buf, buf_bytes, "stream RT=%d C=%d waves=%d S=%d grid=%d d=%lld", pl.RT, pl.C, pl.waves, pl.S,
                      pl.tiles * pl.C, (long long)d_g);

@@ -441,337 +441,6 @@ __device__ __forceinline__ void coop_pipel_body(const SlabParams& p)
 #undef GPFQ_FIN
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// gpfq_pipe2_*: EIGHT rows in TWO groups of four (two interleaved pairs), two phases per step, columns in the register window
-// (round 5).  The four-group kernels of gpfq_pipe_kernels.h sweep one pair per phase: 80 packed instructions and ~42 of
-// per-phase overhead (q out of LDS, the pair's lane tree with its DPP wait states, the LDS word, the weights, the barrier), 488
-// instructions per wave and step -- and with seven sweep waves (two per SIMD) they run AT the SIMD's issue rate: 2 x 488 x 4.45
-// cycles = 2.03 us at 2.1 GHz against 1.96-2.07 measured on the 50-segment rows (profiles/r05_probe_valu.txt).  Two pairs per
-// phase share one four-row lane tree and halve the per-phase overhead: ~410 instructions per wave and step.  The price is the
-// one of gpfq_pipel2 (profiles/r05_probe_pipel_two_groups.txt): a group's exchange has ONE phase -- which is why this kernel is for
-// tiles of <= 32 members only, where publish -> visible -> requested -> landed -> quantized fits the ~1 900 cycles of a phase.
-// Granules as in gpfq_pipel_*: xbuf[tile][parity][group][position][4 rows]; lane layouts of the reducer as pipel_reducer.
-// ------------------------------------------------------------------------------------------------------------------
-template <int MODE, int GV>
-__device__ __forceinline__ void pipe2_reducer(const SlabParams& p, const float* segs, float* qs, int NS, int lane, int tile, int c,
-                                              int C, int nl, int seg_lo, int row0)
-{
-    constexpr int G = 2, RG = 4, RT = 8;
-    constexpr bool FAST = MODE == MODE_MSQ;
-    const int nph = G * p.d;
-    unsigned long long* const xb = p.xbuf + (unsigned)tile * (unsigned)(2 * G * RG) * (unsigned)C;
-    const unsigned block = (unsigned)(C * RG);
-    const int P = pow2_ceil(p.S);
-    const SlotMap smap = make_slot_map(p.S, P, c * nl, 1, lane & 15, nl);
-    const int r16 = lane >> 4;
-    const bool mine = (smap.mask & 1u) != 0;
-    const int seg_word = r16 * NS + (smap.s0 - seg_lo);
-    const int GPL = C > 32 ? C >> 5 : 1;
-    const unsigned pos = (unsigned)(c % GPL) * 32u + (unsigned)(c / GPL);
-    const unsigned pub_off = pos * RG + (unsigned)r16;
-    const unsigned my_xcc = pipe_xcc_id();
-    const unsigned tag = pipe_epoch_tag(p.salt);
-    const kfloat* nrm = as_scalar(p.nrm2);
-    float* hist = qs + RT;
-    const int pair = lane >> 5, j = lane & 31;
-    const int lpr = C / GPL;
-    const bool want = j < lpr;
-    const bool lead = (lane & 15) == 0;
-    const unsigned long long idle = ~__builtin_amdgcn_ballot_w64(want);
-    const unsigned long long unused = ~__builtin_amdgcn_ballot_w64(lead);
-    const unsigned lane_bytes = want ? 32u * (unsigned)j + 16u * (unsigned)pair : 0u;
-    auto request = [&](const unsigned long long* base) {
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c2+3], %0, %1 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV) : "memory");
-        if (GPL >= 2)
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c2+3], %0, %1 offset:1024 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 4) : "memory");
-        if (GPL >= 4) {
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c2+3], %0, %1 offset:2048 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 8) : "memory");
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 v[%c2:%c2+3], %0, %1 offset:3072 sc1" :: "v"(lane_bytes), "s"(base), "n"(GV + 12) : "memory");
-        }
-    };
-    unsigned glo0[4], ghi0[4], glo1[4], ghi1[4];
-    auto read_out = [&]() {
-#define GPFQ_RDL(i)                                                                                                          \
-        asm volatile("v_mov_b32 %0, v[%c4]\n\tv_mov_b32 %1, v[%c4+1]\n\tv_mov_b32 %2, v[%c4+2]\n\tv_mov_b32 %3, v[%c4+3]\n\ts_nop 0" \
-                     : "=v"(glo0[i]), "=v"(ghi0[i]), "=v"(glo1[i]), "=v"(ghi1[i]) : "n"(GV + 4 * i) : "memory");
-        GPFQ_RDL(0)
-        if (GPL >= 2) { GPFQ_RDL(1) }
-        if (GPL >= 4) { GPFQ_RDL(2) GPFQ_RDL(3) }
-#undef GPFQ_RDL
-    };
-    auto all_arrived = [&](unsigned epoch) {
-        unsigned long long ok = __builtin_amdgcn_ballot_w64((ghi0[0] & 0x0fffffffu) == epoch) &
-                                __builtin_amdgcn_ballot_w64((ghi1[0] & 0x0fffffffu) == epoch);
-        if (GPL >= 2)
-            ok &= __builtin_amdgcn_ballot_w64((ghi0[1] & 0x0fffffffu) == epoch) & __builtin_amdgcn_ballot_w64((ghi1[1] & 0x0fffffffu) == epoch);
-        if (GPL >= 4) {
-            ok &= __builtin_amdgcn_ballot_w64((ghi0[2] & 0x0fffffffu) == epoch) & __builtin_amdgcn_ballot_w64((ghi1[2] & 0x0fffffffu) == epoch);
-            ok &= __builtin_amdgcn_ballot_w64((ghi0[3] & 0x0fffffffu) == epoch) & __builtin_amdgcn_ballot_w64((ghi1[3] & 0x0fffffffu) == epoch);
-        }
-        return (ok | idle) == __builtin_amdgcn_read_exec();
-    };
-    bool gave_up = false;
-    if (p.xcd_tiles == 3) __builtin_amdgcn_s_setprio(3);
-    else if (p.xcd_tiles == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p.xcd_tiles == 1) __builtin_amdgcn_s_setprio(1);
-    int ga = 0, ta = 0;                                        // the group swept in the phase before: published AND consumed in this one
-    GPFQ_PSTAMP_DECL
-    for (int ph = 0; ph <= nph; ++ph) {
-        GPFQ_PSTAMP(0)                                       // the barrier
-        if (ph >= 1) {
-            // ---- this member's block of the slot tree for the four rows of the group, published
-            const float val = segs[ga * RG * NS + seg_word];
-            const float vp = wave_tree16_zero_padded(mine ? val : 0.0f);
-            unsigned long long* dst = xb + (unsigned)((ta & 1) * G + ga) * block;
-            const unsigned long long granule = ((unsigned long long)(tag | (my_xcc << 28) | ((unsigned)ta + 1u)) << 32) |
-                                               (unsigned long long)__float_as_uint(vp);
-            if ((lane & 15) == 0) __hip_atomic_store(dst + pub_off, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            GPFQ_PSTAMP(1)                                   // slot tree + publish
-            // ---- the pause (the other members publish in this same phase of theirs), then the request
-            {
-                unsigned w = p.spin_limit & 31u;
-                asm volatile("s_cmp_eq_u32 %0, 0\n\t"
-                             "s_cbranch_scc1 2f\n"
-                             "1:\n\t"
-                             "s_sleep 1\n\t"
-                             "s_sub_u32 %0, %0, 1\n\t"
-                             "s_cmp_lg_u32 %0, 0\n\t"
-                             "s_cbranch_scc1 1b\n"
-                             "2:" : "+s"(w) :: "scc", "memory");
-            }
-            const unsigned long long* src = dst;
-            request(src);
-            // ---- ... and the same group consumed: gather, tree over the members, quantizer, q into LDS before the barrier
-            const unsigned epoch = tag | ((unsigned)ta + 1u);
-            const float n2cur = sload(nrm, 8u * (unsigned)ta);
-            const float in2cur = sload(nrm, 8u * (unsigned)ta + 4u);
-            bool timed_out = false;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            read_out();
-            GPFQ_PSTAMP(2)                                   // pause, request, landing
-            if (__builtin_expect(!all_arrived(epoch), 0)) {
-                unsigned spins = gave_up ? p.spin_limit : 0u;
-                do {
-                    if ((spins += 256) > p.spin_limit) { timed_out = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    request(src);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    read_out();
-                } while (!all_arrived(epoch));
-            }
-            if (ph == 1 && (p.spin_limit >> 8) == 0u) timed_out = true;      // (a limit of zero polls: a deterministic timeout for the tests)
-            GPFQ_PSTAMP(3)                                   // re-polls
-            float x0 = __uint_as_float(glo0[0]), y0 = __uint_as_float(glo1[0]);
-            float x1 = GPL >= 2 ? __uint_as_float(glo0[1]) : 0.0f, y1 = GPL >= 2 ? __uint_as_float(glo1[1]) : 0.0f;
-            float x2 = GPL >= 4 ? __uint_as_float(glo0[2]) : 0.0f, y2 = GPL >= 4 ? __uint_as_float(glo1[2]) : 0.0f;
-            float x3 = GPL >= 4 ? __uint_as_float(glo0[3]) : 0.0f, y3 = GPL >= 4 ? __uint_as_float(glo1[3]) : 0.0f;
-            float x = (x0 + x1) + (x2 + x3), y = (y0 + y1) + (y2 + y3);
-            x = want ? x : 0.0f;
-            y = want ? y : 0.0f;
-            x = xor16_add(wave_tree16_zero_padded(x));
-            y = xor16_add(wave_tree16_zero_padded(y));
-            const float v = (lane & 16) ? y : x;
-            const int rr = ga * RG + (lane >> 4);
-            const bool rvalid = lead && (row0 + rr < p.Ng);
-            const int64_t growl = (int64_t)row0 + (rvalid ? rr : 0);
-            int id;
-            float q;
-            bool redo = false;
-            auto divide_and_quantize = [&]() {
-                const float sarg = (n2cur > 0.0f) ? v / n2cur : 0.0f;
-                q = quantize_mode<MODE>(p, sarg, p.row_id0 + (uint64_t)growl, (uint64_t)ta, id);
-            };
-            if (FAST) redo = !quant_msq_from_dot(v, in2cur, p.inv_step, p.step, p.Kf, p.msq_thr, unused, q, id);
-            else divide_and_quantize();
-            auto commit = [&]() {
-                if (lead) {
-                    qs[rr] = q;
-                    hist[rr * 64 + (ta & 63)] = q;
-                    hist[(RT + rr) * 64 + (ta & 63)] = __int_as_float(id);
-                }
-            };
-            commit();
-            if (FAST && __builtin_expect(redo, 0)) {
-                divide_and_quantize();
-                commit();
-            }
-            if (__builtin_expect((ta & 63) == 63 || ta + 1 == p.d, 0)) {
-                const int t0 = ta & ~63;
-                const int n = ta - t0 + 1;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const int ln = fresh_lane_id();
-                if (c == 0 && ln < n) {
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) {
-                        const int row = ga * RG + r;
-                        if (row0 + row < p.Ng) {
-                            const int64_t gw = (int64_t)row0 + row;
-                            p.Q[gw * p.ldq + t0 + ln] = hist[row * 64 + ln];
-                            if (p.idx) {
-                                const int iv = __float_as_int(hist[(RT + row) * 64 + ln]);
-                                if (p.idx_bytes == 1) reinterpret_cast<int8_t*>(p.idx)[gw * p.ldi + t0 + ln] = (int8_t)iv;
-                                else reinterpret_cast<int16_t*>(p.idx)[gw * p.ldi + t0 + ln] = (int16_t)iv;
-                            }
-                        }
-                    }
-                }
-            }
-            if (__builtin_expect(timed_out && !gave_up, 0) && lane == 0) {
-                atomicExch(p.status, 1);
-                p.status[1] = ta; p.status[2] = tile; p.status[3] = c;
-            }
-            gave_up |= timed_out;
-            if (++ga == G) { ga = 0; ++ta; }
-            GPFQ_PSTAMP(4)                                   // tree over the members, quantizer, q into LDS, rare flush
-        }
-        pipe_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GPFQ_PSTAMP_DUMP(0)
-}
-
-// WB = first register of the window: three x buffers, two a buffers, then the eight residual rows (four interleaved pairs)
-template <int MODE, int WB>
-__device__ __forceinline__ void coop_pipe2_body(const SlabParams& p)
-{
-    constexpr int G = 2, RG = 4, RT = 8;
-    constexpr int X0 = WB, X1 = WB + 16, X2 = WB + 32, A0 = WB + 48, A1 = WB + 64, U0 = WB + 80;
-    extern __shared__ float smem[];                 // seg[RT][NS], qs[RT], history [2 RT][64]
-    const int NW = blockDim.x >> 6;                 // sweep waves + the reducer wave
-    const int NS = NW - 1;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int S = p.S, C = p.C;
-    const int P = pow2_ceil(S);
-    if (*static_cast<volatile const int*>(p.status) != 0) return;
-    const int tile = blockIdx.x / C, c = blockIdx.x % C;
-    const int seg_lo = (c * S + C - 1) / C, seg_hi = ((c + 1) * S + C - 1) / C;
-    const int n_own = seg_hi - seg_lo;
-    const bool active = wave < n_own;
-    const int myseg = seg_lo + (active ? wave : 0);
-    const int nl = P / C;
-    float* segs = smem;                             // [RT][NS]
-    float* qs = smem + RT * NS;                     // [RT], then the Q / idx history [2 RT][64]
-    const int row0 = tile * RT;
-    if (threadIdx.x < RT) qs[threadIdx.x] = 0.0f;   // q_{-1} = 0
-    pipe_barrier();
-    if (wave == NS) {
-        pipe2_reducer<MODE, X0>(p, segs, qs, NS, lane, tile, c, C, nl, seg_lo, row0);
-        return;
-    }
-    const float* xnext = uniform_ptr(p.XT + (int64_t)myseg * kSeg);    // column t+1 while step t runs
-    const float* anext = uniform_ptr(p.AT + (int64_t)myseg * kSeg);
-    const unsigned lane_off = 16u * (unsigned)lane;
-    const kfloat* wrow[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int64_t gr = (int64_t)row0 + ((row0 + r < p.Ng) ? r : (p.Ng - 1 - row0));
-        wrow[r] = as_scalar(p.W + gr * p.ldw);
-    }
-    win_zero16<U0>(); win_zero16<U0 + 16>(); win_zero16<U0 + 32>(); win_zero16<U0 + 48>();
-    win_zero16<U0 + 64>(); win_zero16<U0 + 80>(); win_zero16<U0 + 96>(); win_zero16<U0 + 112>();
-    win_zero16<X0>(); win_zero16<X1>(); win_zero16<X2>(); win_zero16<A0>(); win_zero16<A1>();
-    if (active) {                                   // x_0 -> X0, a_0 -> A0; X2 = x_{-1} = 0 (q_{-1} = 0)
-        win_load16<X0>(xnext, lane_off);
-        win_load16<A0>(anext, lane_off);
-    }
-    float wn[RG];
-#pragma unroll
-    for (int r = 0; r < RG; ++r) wn[r] = wrow[r][0];
-    int t = 0;
-    const int dlast = p.d - 1;
-    GPFQ_PSTAMP_DECL
-
-    // one phase: group g (two pairs) of step t; XP holds x_{t-1}, XC x_t, AC a_t; XN / AN take column t+1
-    auto phase = [&](auto xp_, auto xc_, auto ac_, auto xn_, auto an_, auto g_) {
-        constexpr int XP = decltype(xp_)::value, XC = decltype(xc_)::value, AC = decltype(ac_)::value;
-        constexpr int XN = decltype(xn_)::value, AN = decltype(an_)::value, g = decltype(g_)::value;
-        constexpr int UG = U0 + 16 * RG * g;
-        GPFQ_PSTAMP(0)
-        const float4 qv = *reinterpret_cast<const float4*>(qs + RG * g);
-        const float w0 = wn[0], w1 = wn[1], w2 = wn[2], w3 = wn[3];
-        if constexpr (g == 0) {
-            const int64_t adv = (t + 1 < p.d) ? p.m_pad : 0;
-            xnext += adv;
-            anext += adv;
-        }
-        if (active) {
-            if constexpr (g == 0) win_wait<0>();    // column t has landed (requested in the two phases of step t-1)
-            GPFQ_PSTAMP(1)
-            const v2f a01 = win_sweep16_pair<UG, XP, AC, XC>(qv.x, qv.y, w0, w1);
-            const v2f a23 = win_sweep16_pair<UG + 32, XP, AC, XC>(qv.z, qv.w, w2, w3);
-            GPFQ_PSTAMP(2)
-            const float acc[4] = {a01.x, a01.y, a23.x, a23.y};
-            const float tot = wave_tree64_rows<4>(acc);
-            if ((lane & 15) == 0) segs[(g * RG + (lane >> 4)) * NS + wave] = tot;
-            GPFQ_PSTAMP(3)
-            // half of column t+1 per phase: four requests at a time
-            win_load4<XN, 2 * g>(xnext, lane_off);
-            win_load4<AN, 2 * g>(anext, lane_off);
-            win_load4<XN, 2 * g + 1>(xnext, lane_off);
-            win_load4<AN, 2 * g + 1>(anext, lane_off);
-        }
-        {
-            constexpr int gn = (g + 1) % G;
-            unsigned tn4 = 4u * (unsigned)(g == G - 1 ? (t < dlast ? t + 1 : dlast) : t);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+s"(tn4)::"memory");
-#pragma unroll
-            for (int r = 0; r < RG; ++r) wn[r] = sload(wrow[gn * RG + r], tn4);
-        }
-        GPFQ_PSTAMP(4)
-        pipe_barrier();
-    };
-    auto step = [&](auto xp_, auto xc_, auto ac_, auto xn_, auto an_) -> bool {
-        phase(xp_, xc_, ac_, xn_, an_, std::integral_constant<int, 0>{});
-        phase(xp_, xc_, ac_, xn_, an_, std::integral_constant<int, 1>{});
-        return ++t < p.d;
-    };
-    using I0 = std::integral_constant<int, X0>; using I1 = std::integral_constant<int, X1>; using I2 = std::integral_constant<int, X2>;
-    using J0 = std::integral_constant<int, A0>; using J1 = std::integral_constant<int, A1>;
-    int k = 0;                                       // buffer that holds x_{d-1} when the loop ends
-    for (;;) {
-        k = 0; if (!step(I2{}, I0{}, J0{}, I1{}, J1{})) break;
-        k = 1; if (!step(I0{}, I1{}, J1{}, I2{}, J0{})) break;
-        k = 2; if (!step(I1{}, I2{}, J0{}, I0{}, J1{})) break;
-        k = 0; if (!step(I2{}, I0{}, J1{}, I1{}, J0{})) break;
-        k = 1; if (!step(I0{}, I1{}, J0{}, I2{}, J1{})) break;
-        k = 2; if (!step(I1{}, I2{}, J1{}, I0{}, J0{})) break;
-    }
-    pipe_barrier();                                  // the reducer is one phase behind the last sweep
-    win_wait<0>();
-#ifdef GPFQ_STAMPS
-    if (wave == (p.pace >= 100 ? p.pace - 100 : 0)) { GPFQ_PSTAMP_DUMP(8) }
-#endif
-    if (!active) return;
-    float qlast[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) qlast[r] = qs[r];
-    auto finish = [&](auto xl_) {
-        constexpr int XL = decltype(xl_)::value;     // interleaved pairs: row 2 k + h sits at U0 + 32 k + h, stride 2
-        finish_row_w<U0, XL, 2>(p, qlast[0], row0 < p.Ng, (int64_t)row0, myseg, lane);
-        finish_row_w<U0 + 1, XL, 2>(p, qlast[1], row0 + 1 < p.Ng, (int64_t)row0 + 1, myseg, lane);
-        finish_row_w<U0 + 32, XL, 2>(p, qlast[2], row0 + 2 < p.Ng, (int64_t)row0 + 2, myseg, lane);
-        finish_row_w<U0 + 33, XL, 2>(p, qlast[3], row0 + 3 < p.Ng, (int64_t)row0 + 3, myseg, lane);
-        finish_row_w<U0 + 64, XL, 2>(p, qlast[4], row0 + 4 < p.Ng, (int64_t)row0 + 4, myseg, lane);
-        finish_row_w<U0 + 65, XL, 2>(p, qlast[5], row0 + 5 < p.Ng, (int64_t)row0 + 5, myseg, lane);
-        finish_row_w<U0 + 96, XL, 2>(p, qlast[6], row0 + 6 < p.Ng, (int64_t)row0 + 6, myseg, lane);
-        finish_row_w<U0 + 97, XL, 2>(p, qlast[7], row0 + 7 < p.Ng, (int64_t)row0 + 7, myseg, lane);
-    };
-    if (k == 0) finish(I0{});
-    else if (k == 1) finish(I1{});
-    else finish(I2{});
-}
-
-// <= 8 waves (7 sweep waves + the reducer): 256 registers = window (80 columns + 128 rows) + 48 for the compiler
-#define GPFQ_DEFINE_PIPE2(MODE)                                                                                   \
-    __global__ void __launch_bounds__(64 * 8) __attribute__((amdgpu_num_vgpr(48 / 2)))                            \
-    gpfq_pipe2_m##MODE##_w8(const SlabParams p)                                                                   \
-    {                                                                                                             \
-        asm volatile("" ::: "v255");                                                                              \
-        coop_pipe2_body<MODE, 48>(p);                                                                             \
-    }
-GPFQ_DEFINE_PIPE2(0) GPFQ_DEFINE_PIPE2(1) GPFQ_DEFINE_PIPE2(2) GPFQ_DEFINE_PIPE2(3)
-
 // <= 8 waves (7 sweep waves + the reducer): 256 registers = the window's 192 (twelve residual rows) + 64 for the compiler
 #define GPFQ_DEFINE_PIPEL(MODE)                                                                                   \
     __global__ void __launch_bounds__(64 * 8) __attribute__((amdgpu_num_vgpr(64 / 2)))                            \

@@ -111,81 +111,3 @@ def test_the_other_cooperative_families_stay_selectable(monkeypatch):
     monkeypatch.setenv("GPFQ_COOP_PIPEL", "0")
     assert "pipel" not in _lib.describe_plan(256, 64, 803840) and _lib.describe_plan(256, 64, 803840).startswith("coop RT=4 C=64 waves=13")
     assert "pipe=1" in _lib.describe_plan(1024, 256, 51200)
-
-
-# ---- gpfq_pipe2_*: eight rows in TWO groups of four, two phases per step, one phase per exchange (tiles of <= 32 members) ----
-FORCE2 = {"GPFQ_COOP_PIPE2": "1", "GPFQ_COOP_PIPEL": "0"}
-CASES2 = [
-    ((1024, 12, 51200), {}, "coop RT=8 C=8 waves=7 S=50 grid=256 rounds=4 pipe2=1", "ResNet-50's 14 x 14 maps: seven sweep waves, four rounds"),
-    ((300, 24, 51200), {}, "coop RT=8 C=8 waves=7 S=50 grid=256 rounds=2 pipe2=1", "the last round partial, the last tile with 4 valid rows"),
-    ((70, 16, 201728), {}, "coop RT=8 C=32 waves=7 S=197 grid=256 rounds=2 pipe2=1", "32 members: all 32 lanes of a row pair's gather"),
-    ((2048, 6, 13312), {}, "coop RT=8 C=2 waves=7 S=13 grid=256 rounds=2 pipe2=1", "two members per tile"),
-    ((256, 10, 26624), {"GPFQ_COOP_C": "8"}, "coop RT=8 C=8 waves=4 S=26 grid=256 pipe2=1", "four sweep waves: one per SIMD"),
-    ((128, 12, 93184), {"GPFQ_COOP_C": "16"}, "coop RT=8 C=16 waves=6 S=91 grid=256 pipe2=1", "six sweep waves, 16 members"),
-    ((24, 20, 26624), {"GPFQ_COOP_C": "4"}, "coop RT=8 C=4 waves=7 S=26 grid=12 pipe2=1", "four members of 6 / 7 segments"),
-    ((13, 9, 3072), {"GPFQ_COOP_C": "2", "plan": "3"}, "coop RT=8 C=2 waves=2 S=3 grid=4 pipe2=1", "two sweep waves, members of 1 and 2 segments; 5 valid rows in the last tile"),
-    ((16, 1, 26624), {"GPFQ_COOP_C": "8"}, "coop RT=8 C=8 waves=4 S=26 grid=16 pipe2=1", "ONE column"),
-    ((16, 2, 26624), {"GPFQ_COOP_C": "8"}, "coop RT=8 C=8 waves=4 S=26 grid=16 pipe2=1", "two columns"),
-    ((16, 7, 26624), {"GPFQ_COOP_C": "8"}, "coop RT=8 C=8 waves=4 S=26 grid=16 pipe2=1", "seven columns: the buffer rotation past one period"),
-    ((16, 131, 20000), {"GPFQ_COOP_C": "4"}, "coop RT=8 C=4 waves=5 S=20 grid=8 pipe2=1", "three Q / idx history flushes, the last partial"),
-]
-
-
-@pytest.mark.parametrize("shape,env,plan_desc,why", CASES2, ids=["%dx%dx%d_%s" % (c[0] + ("_".join(c[2].split()[2:4]),)) for c in CASES2])
-def test_two_group_pipelined_kernels_equal_oracle_and_streaming(oracle_mod, monkeypatch, shape, env, plan_desc, why):
-    from quantized_neural_nets_amd import _lib
-    N, d, m = shape
-    env = dict(env)
-    plan = int(env.pop("plan", "0"))
-    for k, v in dict(FORCE2, **env).items():
-        monkeypatch.setenv(k, v)
-    assert _lib.describe_plan(N, d, m, 1, plan).startswith(plan_desc), _lib.describe_plan(N, d, m, 1, plan)
-    W, A, X = bw.synthetic_layer(N, d, m, 555 + N + d, first_layer=False)
-    step = bw.layer_step(W)
-    r = _run(W, A, X, m, plan, step=step)
-    assert r["timeouts"] == []
-    Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8)
-    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
-    assert np.array_equal(r["Q"].cpu().numpy().view(np.uint32), Q.view(np.uint32))
-    assert np.array_equal(r["U"].cpu().numpy(), U)
-    st = _run(W, A, X, m, 1, step=step)
-    assert torch.equal(st["idx"], r["idx"]) and torch.equal(st["U"], r["U"]) and torch.equal(st["usq_seg"], r["usq_seg"])
-    r2 = _run(W, A, X, m, plan, step=step)
-    assert r2["timeouts"] == [] and torch.equal(r2["idx"], r["idx"]) and torch.equal(r2["U"], r["U"])
-
-
-@pytest.mark.parametrize("mode", ["soft", "hard", "stochastic"])
-def test_two_group_pipelined_kernels_other_quantizers(oracle_mod, monkeypatch, mode):
-    from quantized_neural_nets_amd import _lib
-    for k, v in FORCE2.items():
-        monkeypatch.setenv(k, v)
-    omode = {"soft": oracle_mod.MODE_SOFT, "hard": oracle_mod.MODE_HARD, "stochastic": oracle_mod.MODE_STOCHASTIC}[mode]
-    lmode = {"soft": _lib.MODE_SOFT, "hard": _lib.MODE_HARD, "stochastic": _lib.MODE_STOCHASTIC}[mode]
-    for (N, d, m) in ((300, 8, 51200), (70, 9, 201728)):
-        desc = _lib.describe_plan(N, d, m, 1, 0, lmode)
-        assert "pipe2=1" in desc, desc
-        W, A, X = bw.synthetic_layer(N, d, m, 29 + N, first_layer=False)
-        step = bw.layer_step(W)
-        r = _run(W, A, X, m, 0, mode=mode, seed=77, step=step)
-        assert r["timeouts"] == []
-        Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8, mode=omode, lamb=0.05, seed=77)
-        assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx)
-        assert np.array_equal(r["U"].cpu().numpy(), U)
-
-
-def test_two_group_pipelined_timeout_is_reported_and_the_layer_redone(oracle_mod, monkeypatch):
-    from quantized_neural_nets_amd import _lib
-    for k, v in FORCE2.items():
-        monkeypatch.setenv(k, v)
-    N, d, m = 48, 12, 51200
-    monkeypatch.setenv("GPFQ_COOP_C", "8")
-    assert "pipe2=1" in _lib.describe_plan(N, d, m)
-    W, A, X = bw.synthetic_layer(N, d, m, 5, first_layer=False)
-    step = bw.layer_step(W)
-    monkeypatch.setenv("GPFQ_COOP_SPIN_LIMIT", "0")
-    r = _run(W, A, X, m, 0, step=step)
-    assert r["timeouts"] == [(N, d, m)]
-    Q, idx, U = oracle_mod.quantization(W.numpy(), A.numpy(), X.numpy(), float(r["step"]), 8)
-    assert np.array_equal(r["idx"].cpu().numpy().astype(np.int16), idx) and np.array_equal(r["U"].cpu().numpy(), U)
-    monkeypatch.delenv("GPFQ_COOP_SPIN_LIMIT")
-    assert _run(W, A, X, m, 0, step=step)["timeouts"] == []
