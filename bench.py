@@ -359,6 +359,8 @@ def roofline_bound(fam, prep_ms_per_step, prep_bytes_per_step, steps, capture):
         tot_floor += fl
     return {"frac": round(tot_floor / tot_ms, 4), "floor_ms_per_step": round(tot_floor, 3), "ms_per_step": round(tot_ms, 3),
             "families": terms,
+            # (a family measured FASTER than its floor would mean the roof is wrong, not that the kernel is good)
+            "floors_exceeded": sorted(k for k, v in terms.items() if v["frac"] is not None and v["frac"] > 1.0),
             "definition": "sum over kernel families of (the floor the family's binding roof sets on its work) / sum of their measured "
                           "times (events on the launch stream): <= 1 by construction.  Roofs: vector ALU = packed fp32 instructions "
                           "of the sweeps x 4.45 SIMD cycles with two waves per SIMD, 5.2 per instruction of a single wave, at 2.4 GHz; "
@@ -376,7 +378,7 @@ def plan_rounds(desc):
     return int(kv.get("rounds", "1"))
 
 
-def l2_column_bytes(desc, N, d, m_pad, groups=1):
+def l2_column_bytes(desc, N, d, m_pad, groups=1, m=None):
     """Bytes of activation columns the workgroups of a register-resident launch pull from L2 over the whole loop: every
     workgroup (a tile of RT rows, or one of the C members of a tile) requests x_t and a_t for its own segments each
     step -- 8 * m_pad bytes per row TILE per step, whatever C is.  None for the streaming kernels (HBM-bound)."""
@@ -386,10 +388,10 @@ def l2_column_bytes(desc, N, d, m_pad, groups=1):
     kv = dict(x.split("=") for x in w[1:] if "=" in x)
     rt = int(kv["RT"])
     Ng = N // groups
-    if w[0] == "resident" and int(kv.get("S", "0")) == 1:
-        tiles = groups * (-(-Ng // rt))           # one-segment rows: one wave per RT rows
-    else:
-        tiles = groups * (-(-Ng // rt))
+    tiles = groups * (-(-Ng // rt))               # (one-segment rows: one wave per RT rows)
+    if w[0] == "resident" and int(kv.get("S", "0")) == 1 and m is not None and m <= 512:
+        # one-segment rows of m <= 256 / 512 samples: the variants that load (and sweep) one / two quarters of the segment
+        return tiles * d * 8 * (256 if m <= 256 else 512)
     return tiles * d * 8 * m_pad
 
 
@@ -920,7 +922,7 @@ def main():
         desc = _lib.describe_plan(max(Nl, 1), dg, m, gl if Nl % gl == 0 else 1, args.plan)
         kind = kernel_name(desc, mode)
         mp = _lib.lib.gpfq_padded_m(m)
-        l2b = l2_column_bytes(desc, max(Nl, 1), dg, mp, gl if Nl % gl == 0 else 1)
+        l2b = l2_column_bytes(desc, max(Nl, 1), dg, mp, gl if Nl % gl == 0 else 1, m)
         ab = bw.algorithmic_bytes(Nl, dg, m, gl if Nl % gl == 0 else 1)
         f = fam.setdefault(kind, {"ms": 0.0, "bytes": 0.0, "launches": 0, "l2": 0.0, "l2_known": True, "floor_ms": 0.0, "roofs": {}})
         roof_name, floor_ms = roof_floor_ms(desc, dg, gl, ab, l2b)

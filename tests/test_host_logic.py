@@ -360,6 +360,10 @@ def test_bench_quotes_only_a_pmc_summary_of_its_own_kernel_sources(tmp_path, mon
     assert bench.plan_rounds("coop RT=4 C=8 waves=12 S=91 grid=256 d=1152") == 1
     assert bench.l2_column_bytes("resident RT=2 waves=7 S=7 grid=(256,1) d=4608", 512, 4608, 7168) == 256 * 4608 * 8 * 7168
     assert bench.l2_column_bytes("stream RT=4 waves=8 S=50 grid=(320,1) d=320", 1280, 320, 51200) is None
+    # one-segment rows of m <= 256 / 512 samples: the kernels load one / two quarters of the padded segment
+    assert bench.l2_column_bytes("resident RT=2 waves=1 S=1 grid=(2048,1) d=4096", 4096, 4096, 1024, 1, 512) == 2048 * 4096 * 8 * 512
+    assert bench.l2_column_bytes("resident RT=1 waves=1 S=1 grid=(1000,1) d=512", 1000, 512, 1024, 1, 256) == 1000 * 512 * 8 * 256
+    assert bench.l2_column_bytes("resident RT=1 waves=1 S=1 grid=(1000,1) d=2048", 1000, 2048, 1024, 1, 1024) == 1000 * 2048 * 8 * 1024
 
 
 def test_division_free_msq_form_equals_the_division_form(tmp_path):
@@ -467,7 +471,7 @@ def test_bench_roofline_bound_holds_every_family_against_the_roof_that_binds_it(
     fam = {"a": {"ms": 20.0, "floor_ms": 10.0, "roofs": {"vector ALU": 10.0}}, "b": {"ms": 10.0, "floor_ms": 8.0, "roofs": {"vector L1": 8.0}}}
     rb = bench.roofline_bound(fam, 2.0, 8e9, 10, False)
     assert rb["families"]["column preparation"]["frac"] == 0.5 and rb["families"]["a"]["roof"] == "vector ALU"
-    assert abs(rb["frac"] - (1.0 + 0.8 + 1.0) / (2.0 + 1.0 + 2.0)) < 1e-4 and rb["frac"] <= 1.0
+    assert abs(rb["frac"] - (1.0 + 0.8 + 1.0) / (2.0 + 1.0 + 2.0)) < 1e-4 and rb["frac"] <= 1.0 and rb["floors_exceeded"] == []
     for src in rb["sources"].values():
         if src.startswith("profiles/"):
             assert os.path.exists(os.path.join(ROOT, src.split(" ")[0])), src
