@@ -330,7 +330,7 @@ def roof_floor_ms(desc, dg, groups, ab, l2b):
             return "vector L1", l1
         valu = dg * us(pair_or_single(rt)) * 1e-3
         return ("vector L1", l1) if l1 >= valu else ("vector ALU", valu)
-    steps = dg * rounds * (1 if "groups" not in kv else 1)
+    steps = dg * rounds                              # (one row per group, depthwise: every row walks its own d columns)
     if kv.get("pipel") == "1":
         return "vector ALU", steps * 3 * us(160) * 1e-3
     if kv.get("pipe") == "1":

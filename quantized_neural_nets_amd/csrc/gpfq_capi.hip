@@ -262,7 +262,7 @@ bool choose_coop(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
     // exists; default: where modelled cheaper -- layers in rounds, whose rounds they cut by a third)
     // (GPFQ_COOP_PIPE=0, "no pipelined kernels", switches this family off too unless it is asked for by name)
     const int pipel_mode = env_int("GPFQ_COOP_PIPEL", pipe_mode == 0 ? 0 : -1);
-    if (pipel_mode != 0 && allow_pipe && !force_rt) {
+    if (pipel_mode != 0 && allow_pipe && (!force_rt || force_rt == gpfq::kPipelRows)) {
         Plan pp = *pl;
         double pcost = 0.0;
         // (by more than 3 %: at a modelled tie the measured one goes to the four-group kernels -- 256 rows of 197 segments
@@ -618,6 +618,7 @@ gpfq::SlabParams make_slab_params(const Plan& pl, const gpfq::LoopParams& p, boo
     sp.xcd_tiles = 0;                               // launch_coop decides
     sp.seed = p.qc.seed; sp.row_id0 = p.row_id0;
     sp.salt = 0; sp.allow_local = 0;                // launch_pipe sets them
+    sp.reducer_prio = 0;                            // launch_pipel sets it
     sp.prefetch_ahead = 0; sp.prefetch_lines = 1;   // launch_resident decides
     return sp;
 }
@@ -830,8 +831,15 @@ int launch_pipel(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scr
     SlabKernel kern = pipel_kernel(mode);
     const int threads = 64 * (pl.waves + 1);                           // + the reducer wave
     const size_t shm = gpfq::pipel_lds_bytes(pl.waves);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (e != hipSuccess) return hip_fail(e, "dynamic LDS size");
+    hipError_t e = hipSuccess;
+    {   // more than 64 KB of dynamic LDS: allowed once per kernel (for the largest workgroup: seven sweep waves)
+        static std::atomic<int> attr_set[4];
+        if (!attr_set[mode & 3].load(std::memory_order_acquire)) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpfq::pipel_lds_bytes(7));
+            if (e != hipSuccess) return hip_fail(e, "dynamic LDS size");
+            attr_set[mode & 3].store(1, std::memory_order_release);
+        }
+    }
     const int cus = device_cu_count();
     const int nblocks = pl.tiles * pl.C;
     int nb = 0;
@@ -847,7 +855,8 @@ int launch_pipel(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scr
     // low five bits: the reducer's pause in front of its gather request, in units of 64 clocks (gpfq_pipel_kernels.h (c))
     // (measured: 8 x 64 clocks and priority 2 are the best or within the noise of it at 2 / 8 / 32 / 128 members)
     spx.spin_limit = (sp.spin_limit & ~255u) | ((unsigned)env_int("GPFQ_PIPEL_REQUEST_PAUSE", 8) & 31u);
-    spx.xcd_tiles = env_int("GPFQ_PIPEL_REDUCER_PRIO", 2) & 3;               // (the reducer wave's issue priority)
+    spx.xcd_tiles = 0;
+    spx.reducer_prio = env_int("GPFQ_PIPEL_REDUCER_PRIO", 2) & 3;
     static std::atomic<unsigned> launch_number{0};
     spx.salt = launch_number.fetch_add(1) & 255u;
     spx.allow_local = 0;

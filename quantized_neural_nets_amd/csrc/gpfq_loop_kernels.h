@@ -103,6 +103,7 @@ struct SlabParams {
     int prefetch_ahead; // resident kernels: columns the prefetch agent (one extra wave, active in one workgroup per XCD) runs ahead of the sweeps; 0 = no agent wave
     unsigned salt;     // pipelined kernels: 8-bit launch number carried in every granule's epoch word (a line left behind by an earlier launch never matches)
     int allow_local;   // pipelined kernels: members of a tile that find themselves on ONE XCD may publish with plain stores (the XCD's L2 is their coherence point)
+    int reducer_prio;  // twelve-row pipelined kernels: the reducer wave's issue priority (s_setprio 0 .. 3)
 };
 
 template <int MODE>

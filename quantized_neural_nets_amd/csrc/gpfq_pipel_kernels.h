@@ -58,8 +58,8 @@ __device__ __forceinline__ void pipel_dma(const float* gbase /* wave-uniform */,
                  "global_load_lds_dwordx4 %0, %1 offset:1024\n\t"
                  "global_load_lds_dwordx4 %0, %1 offset:2048\n\t"
                  "global_load_lds_dwordx4 %0, %1 offset:3072"
-                 :: "v"(lane_off), "s"(gbase), "s"(lds_byte_addr) : "memory");
-}
+                 :: "v"(lane_off), "s"(gbase), "s"(lds_byte_addr) : "memory", "m0");     // (m0 is reserved: the compiler sets it in front of
+}                                                                                         //  every use of its own and keeps nothing in it)
 __device__ __forceinline__ void pipel_wait_columns() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // The reducer wave: 3 d + 2 phases.  Phase ph: (a) publish the group swept in phase ph-1; (b) consume the gather of the
@@ -131,9 +131,9 @@ __device__ __forceinline__ void pipel_reducer(const SlabParams& p, const float* 
     bool gave_up = false;
     // the reducer's issue priority (the host's choice, launch_pipel): a short dependent chain among long sweeps -- but it shares
     // its SIMD with a sweep wave, whose instructions it then delays
-    if (p.xcd_tiles == 3) __builtin_amdgcn_s_setprio(3);
-    else if (p.xcd_tiles == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p.xcd_tiles == 1) __builtin_amdgcn_s_setprio(1);
+    if (p.reducer_prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (p.reducer_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.reducer_prio == 1) __builtin_amdgcn_s_setprio(1);
     // the running (group, column) of the three parts: (a) / (c) the group swept in phase ph-1, (b) the one swept in phase ph-2
     int ga = 0, ta = 0, gb = 0, tb = 0;
     GPFQ_PSTAMP_DECL

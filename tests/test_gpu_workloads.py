@@ -82,6 +82,7 @@ import os, sys
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
 import numpy as np, torch, torch.distributed as td
 import golden_inputs as gi
+from quantized_neural_nets_amd import _lib
 from quantized_neural_nets_amd import StepAlgorithm as SA, dist as qd
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
@@ -96,10 +97,15 @@ try:
         qd.disable()
         plain = SA._quantize_layer_ex(*args)
         assert plain["rows"] is None
-        qd.enable(force=True)
+        ctx = qd.enable(force=True)
         assert qd.active() is not None and qd.active().world == 1
+        # the device's host lock (scratch -> launch -> status read, _lib.exclusive) is released before the collective: a rank
+        # blocked in the all_gather while holding it would deadlock a peer rank living in another thread on the same card
+        held = []
+        ctx.event_hook = lambda tag: held.append((tag, _lib.exclusive(dev)._is_owned()))
         sh = SA._quantize_layer_ex(*args)
         torch.cuda.synchronize()
+        assert [t for t, _ in held] == ["collective_begin", "collective_end"] and not any(h for _, h in held), held
         assert sh["rows"] is not None and sh["rows"].numel() == W.shape[0]          # the sharded path ran
         assert torch.equal(sh["idx"], plain["idx"]) and torch.equal(sh["Q"], plain["Q"]) and torch.equal(sh["U"], plain["U"]), name
         assert np.array_equal(sh["idx"].cpu().numpy().astype(np.int16), fx["idx"]), name
