@@ -99,3 +99,31 @@ def test_full_size_four_row_cooperative_shapes(oracle_mod, monkeypatch, shape, k
                                 X[:, :256].contiguous().to(DEV), shape[2], 1.16 / 8, 8, 1, None, 0.1, 1, False,
                                 torch.device(DEV), step_override=float(full["step"]), compute_errors=False)
     assert torch.equal(pre["idx"], full["idx"][:, :256])
+
+
+@pytest.mark.parametrize("shape,plan", [((256, 64, 803840), "coop RT=12 C=128 waves=7 S=785 grid=256 rounds=11 pipel=1"),
+                                        ((1024, 512, 201728), "coop RT=12 C=32 waves=7 S=197 grid=256 rounds=11 pipel=1")])
+def test_full_size_layers_in_rounds_on_the_twelve_row_kernels(oracle_mod, shape, plan):
+    """ResNet-50 layer1.x.conv3 / downsample (N = 256, m = 803 840: eleven rounds of two twelve-row tiles on 128 members) and
+    layer3.0.downsample (N = 1024, m = 201 728: eleven rounds of eight tiles on 32 members, first 96 of its 512 columns) at batch 1024, the
+    shapes the round-5 family was built for: AUTO == streaming bit for bit (indices, Q, U, the fused sums of squares), rows
+    [a, b) alone == the slice of the full result (another tiling, other rounds: the neuron-shard property), and the first and
+    last tile's rows == the CPU oracle."""
+    from quantized_neural_nets_amd import _lib
+    N, d, m = shape
+    dl = min(d, 96)
+    assert _lib.describe_plan(N, dl, m).startswith(plan), _lib.describe_plan(N, dl, m)
+    W, A, X, full = _layer(0, shape, 1234 + 21, d_limit=dl)
+    assert full["timeouts"] == []
+    _, _, _, st = _layer(1, shape, 1234 + 21, d_limit=dl)
+    assert torch.equal(st["idx"], full["idx"]) and torch.equal(st["U"], full["U"]) and torch.equal(st["Q"], full["Q"])
+    assert torch.equal(st["usq_seg"], full["usq_seg"])
+    del st
+    _, _, _, part = _layer(0, shape, 1234 + 21, rows=(7, 100), d_limit=dl)
+    assert torch.equal(part["idx"], full["idx"][7:100]) and torch.equal(part["U"], full["U"][7:100])
+    del part
+    rows = list(range(12)) + list(range(N - 12, N))
+    Q, idx, U = oracle_mod.quantization(W[rows].numpy(), A.numpy(), X.numpy(), float(full["step"]), 8)
+    ridx = torch.tensor(rows, device=DEV)
+    assert np.array_equal(full["idx"].index_select(0, ridx).cpu().numpy().astype(np.int16), idx)
+    assert np.array_equal(full["U"].index_select(0, ridx).cpu().numpy(), U)
