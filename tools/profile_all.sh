@@ -6,6 +6,9 @@
 #   2. rocprofv3 --kernel-trace --stats of the headline, two PMC passes for the HBM-side traffic (tools/profile_bench.sh)
 #   3. the counter passes behind roofline_issue / the measured roofline_l2 (tools/profile_counters.sh)
 #   4. rocprofv3 kernel statistics of r50_all and effnet_b1 (tools/profile_workload.sh)
+# Since round 5 the whole set takes ~25 minutes, more than one 20-minute GPU call: use tools/profile_part1.sh and
+# tools/profile_part2.sh (the same steps in two calls; part 2 copies the counter summaries into profiles/ on the box and re-runs the
+# lines that quote them).  This script remains for a box without that limit.
 TAG=${1:-r03_v1}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
