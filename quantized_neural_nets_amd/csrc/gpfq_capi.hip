@@ -351,8 +351,8 @@ bool choose_pipe(int64_t Ng, int S, int cus, int mode, Plan* pl, double* cost_ou
 // sweep of one group -- four rows, two interleaved pairs: 160 packed instructions per sweep wave -- on the fullest SIMD plus
 // the lane tree, the LDS word and the barrier; the exchange hides under it.  (First measurements, round 5: see profiles/NOTES.md.)
 // Measured per column and round (tools/layer_bench.py, round 5): 128 members x 7 waves 3.67, 32 x 7 3.2-3.3, 8 x 7 3.3-3.4,
-// 2 x 7 3.34, 64 x 5 3.0.  What bounds a phase is the vector ALU: 250 instructions per sweep wave, two sweep waves per SIMD,
-// 4.9 cycles each (v_pk_fma_f32 takes two passes) = 2 400 cycles.
+// 2 x 7 3.34, 64 x 5 3.0.  What bounds a phase is the SIMD's issue rate: 250 instructions per sweep wave (160 of them packed, 4.45
+// SIMD cycles each with two waves on the SIMD: profiles/r05_probe_valu.txt), two sweep waves per SIMD: ~2 400 cycles.
 double pipel_step_cost(int waves, int C)
 {
     const int per_simd = (waves + 3) / 4;
@@ -832,12 +832,13 @@ int launch_pipel(const Plan& pl, const gpfq::SlabParams& sp, int mode, void* scr
     const int threads = 64 * (pl.waves + 1);                           // + the reducer wave
     const size_t shm = gpfq::pipel_lds_bytes(pl.waves);
     hipError_t e = hipSuccess;
-    {   // more than 64 KB of dynamic LDS: allowed once per kernel (for the largest workgroup: seven sweep waves)
-        static std::atomic<int> attr_set[4];
-        if (!attr_set[mode & 3].load(std::memory_order_acquire)) {
+    {   // more than 64 KB of dynamic LDS: allowed once per (device, kernel), for the largest workgroup (seven sweep waves)
+        static std::atomic<int> attr_set[64][4];
+        const int dev = current_device_slot();
+        if (dev < 0 || !attr_set[dev][mode & 3].load(std::memory_order_acquire)) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpfq::pipel_lds_bytes(7));
             if (e != hipSuccess) return hip_fail(e, "dynamic LDS size");
-            attr_set[mode & 3].store(1, std::memory_order_release);
+            if (dev >= 0) attr_set[dev][mode & 3].store(1, std::memory_order_release);
         }
     }
     const int cus = device_cu_count();

@@ -30,6 +30,10 @@
 //     (The 256-granule gather of gpfq_pipe_rg2_*_w8sq reads lines that hold all four groups, a quarter of each used, from 128
 //     members at once: 4.65 us per column and round, profiles/NOTES.md round 4.)
 //
+// Built, bit-exact and measured SLOWER (round 5, not kept): two groups of six rows (a group's exchange then has one phase, not two)
+// and LDS-word dataflow synchronisation instead of the barrier per phase -- profiles/r05_probe_pipel_two_groups.txt,
+// profiles/r05_probe_pipel_dataflow.txt.
+//
 // Bit-exactness is untouched: per row the same sweep (win_sweep4_pair_lds), the same lane tree, the same slot tree split at the
 // same member boundaries, the same quantizer -- only interleaved differently in time (tests/test_gpu_pipel.py).
 #pragma once
