@@ -77,6 +77,10 @@ def parse_args():
     ap.add_argument("--prefetch-analog", action="store_true",
                     help="prepare the ANALOG columns of layer i+1 on a side stream while the loop of layer i runs (they do not "
                          "depend on the layers quantized before; the quantized columns stay serial, as in the real driver)")
+    ap.add_argument("--status-per-layer", action="store_true",
+                    help="read the cooperative kernels' status word (a host synchronisation) after every layer, as the driver "
+                         "does, instead of once per step: the layers of a step are independent here, so a step queues them back "
+                         "to back, reads the word once and redoes the step layer by layer if a launch gave up")
     ap.add_argument("--driver", default=None, choices=["r18", "r50", "vgg16", "effnet_b1"],
                     help="time QuantizeNeuralNet.quantize_network() itself -- what the reference's main.py:120-125 times -- on a "
                          "builder-owned ResNet-18 (batch 256) / ResNet-50 (batch 1024) with random weights and synthetic "
@@ -782,23 +786,42 @@ def main():
             ctypes.c_void_p(T.data_ptr()), mp, _lib.current_stream_ptr(dev)))
         return PreparedColumns(T, m)
 
-    def run_layer(name, W, A, X, step, m, plan_, hook_):
+    def run_layer(name, W, A, X, step, m, plan_, hook_, check_status=True):
         if args.capture:
             fa, fx_, geom, sel = A
             if hook_:
                 hook_("prepare_begin", None)
             A, X = gather(fa, geom, sel, m), gather(fx_, geom, sel, m)
             r = StepAlgorithm._quantize_layer_ex(W, A, X, m, 1.16 / K, K, 1, reg, lamb, groups_of[name], False, dev,
-                                                 compute_errors=False, step_override=step, plan=plan_,
+                                                 compute_errors=False, step_override=step, plan=plan_, check_status=check_status,
                                                  event_hook=(lambda tag, s: hook_(tag, s) if tag != "prepare_begin" else None) if hook_ else None)
         else:
             r = StepAlgorithm._quantize_layer_ex(W, A, X, m, 1.16 / K, K, 1, reg, lamb, groups_of[name], False, dev,
-                                                 compute_errors=False, step_override=step, plan=plan_, event_hook=hook_)
+                                                 compute_errors=False, step_override=step, plan=plan_, event_hook=hook_,
+                                                 check_status=check_status)
         return r
 
     side = torch.cuda.Stream(device=dev) if args.prefetch_analog and not args.capture else None
 
     def one_step(keep=False):
+        # The layers of a step do not feed each other here (synthetic inputs, resident before the step), so the step queues
+        # them back to back and reads the cooperative kernels' status word ONCE, at its end (StepAlgorithm's
+        # check_status=False: "for callers that neither consume nor forward the outputs before that"); a step in which a
+        # launch gave up is redone layer by layer, every layer checked and redone on the streaming plan as the driver does.
+        if args.status_per_layer:
+            return one_pass(keep, True)
+        one_pass(keep, False)
+        ok = _lib.status_ok(dev)
+        if pg:
+            # a redone step repeats its all_gathers: every rank must take the same branch
+            flag = torch.tensor([1 if ok else 0], device=dev if args.backend == "nccl" else "cpu", dtype=torch.int32)
+            td.all_reduce(flag, op=td.ReduceOp.MIN)
+            ok = bool(flag.item())
+        if not ok:
+            timeouts.append("a launch of the step gave up: step redone with the status read after every layer")
+            one_pass(keep, True)
+
+    def one_pass(keep, check_status):
         ahead = {}                                   # layer position -> (PreparedColumns, event on the side stream)
         main = torch.cuda.current_stream(dev)
         for i, (name, W, A, X, step, m) in enumerate(data):
@@ -824,7 +847,7 @@ def main():
                                 dn = torch.cuda.Event()
                                 dn.record(side)
                             ahead[i + 1] = (Pn, dn)
-            r = run_layer(name, W, A, X, step, m, plan, hook_i)
+            r = run_layer(name, W, A, X, step, m, plan, hook_i, check_status)
             timeouts.extend(r["timeouts"])
             if keep:
                 last_idx[name] = r["idx"]
@@ -843,16 +866,21 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    for _ in range(args.warmup):
-        one_step()
+    for w in range(args.warmup):
+        one_step(keep=(w == args.warmup - 1))     # (the kept indices' blocks exist before the timed region: no hipMalloc in it)
     fence()
     del timeouts[:]
+    last_idx.clear()                              # (their blocks go back to the caching allocator for the timed region's keep)
     cur["on"] = True
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for s in range(args.steps):
         one_step(keep=(s == args.steps - 1))
     fence()
     elapsed = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(dev)
+    # hipMalloc / hipFree inside the timed region synchronise the device: a steady-state step should need none
+    device_allocs = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
     elapsed_local = elapsed
     cur["on"] = False
     gc.enable()
@@ -1036,6 +1064,8 @@ def main():
                        "algorithmic_bytes": sum(alg_bytes.values()),
                        "column_prep": "fused patch gather from feature maps (driver path)" if args.capture else
                                       "transpose of (m, d) matrices" + ("; analog columns one layer ahead on a side stream" if side is not None else ""),
+                       "status_read": "after every layer (host synchronisation)" if args.status_per_layer else
+                                      "once per step: the step's layers queued back to back; a step with a timed-out launch is redone layer by layer",
                        "parallelism": ("neuron-shard x%d + all_gather(int8 idx)" % world if world > 1 else
                                        "single GPU, sharded path forced (one-rank %s group)" % args.backend if args.force_shard else "single GPU")},
             "roofline_whole_job_frac": round(sum(alg_bytes.values()) * args.steps / elapsed / 1e9 / HBM_PEAK_GBPS / max(world, 1), 4),
@@ -1044,6 +1074,7 @@ def main():
             "per_rank": per_rank,
             **({"expected": expected_per_rank(args.workload, world)} if world > 1 else {}),
             "cooperative_timeouts": len(timeouts),
+            "device_allocations_in_timed_region": device_allocs,
             "roofline": roofline,
             "roofline_l2": roofline_l2,
             "roofline_issue": roofline_issue,
