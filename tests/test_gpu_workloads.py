@@ -22,8 +22,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra, timeout=850, shared_card=False):
+def run_bench(*extra, timeout=850, shared_card=False, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + list(extra)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-4000:]
@@ -71,6 +72,22 @@ def test_resnet50_all_distinct_layer_shapes():
     assert rec["oracle_shape_check"]["shapes"] == rec["config"]["layers"]
     assert "gpfq_pipel_m0_w8" in rec["roofline"]["families"] and "gpfq_pipe_rg2_m0_w8s" in rec["roofline"]["families"]
     assert 0 < rec["roofline_bound"]["frac"] <= 1.0 and rec["roofline_bound"]["families"]["gpfq_pipel_m0_w8"]["roof"] == "vector ALU"
+
+
+def test_step_with_a_timed_out_launch_is_redone_layer_by_layer():
+    """bench.py queues the (independent) layers of a step back to back and reads the cooperative kernels' status word once per
+    step; a step in which a launch gave up (here every cooperative one: spin limit 0) is redone with the read after every layer,
+    where each timed-out layer is redone on the streaming plan (step_algorithm.py run_rows) -- the step's indices equal the
+    streaming rerun's and the oracle's, the timeouts are counted.  --status-per-layer: the same result with the read per layer."""
+    forced = {"GPFQ_COOP_SPIN_LIMIT": "0"}
+    rec, err = run_bench("--max-cols", "24", shared_card=True, env_extra=forced)
+    assert "once per step" in rec["config"]["status_read"]
+    assert rec["cooperative_timeouts"] >= 1 + 8          # the step, then the eight cooperative layers of its redo
+    assert rec["output_check"]["layers"] == 16 and rec["oracle_shape_check"]["shapes"] == 7
+    rec2, err = run_bench("--max-cols", "24", "--status-per-layer", shared_card=True, env_extra=forced)
+    assert "after every layer" in rec2["config"]["status_read"] and rec2["cooperative_timeouts"] == 8
+    rec3, err = run_bench("--max-cols", "24")
+    assert rec3["cooperative_timeouts"] == 0 and rec3["device_allocations_in_timed_region"]["num_alloc_retries"] == 0
 
 
 def test_sharded_path_through_rccl_equals_unsharded(tmp_path):
